@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liboracle.so (the plain-C CPU restatement).
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+PASSES = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]   # EncoderContext.cpp:9057-9093
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", HERE, "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    lib.yko_enc_create.restype = vp
+    lib.yko_enc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.yko_enc_destroy.argtypes = [vp]
+    lib.yko_mip_prefilter.argtypes = [vp]
+    lib.yko_get_bounds.argtypes = [vp, vp]
+    for name in ("yko_mip_bitmap", "yko_last_bitmap", "yko_last_rgb_stream", "yko_1d_pix_stream", "yko_1d_type_stream",
+                 "yko_last_tile_defs"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, ip]
+    lib.yko_last_nibbles.restype = vp
+    lib.yko_last_nibbles.argtypes = [vp, ip, ip]
+    lib.yko_fitting_quad_smooth.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    for name in ("yko_smooth_map", "yko_mipmap_mask"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp]
+    for name in ("yko_map_smooth_tile", "yko_preview"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, C.c_int]
+    lib.yko_dynamic_tile_encode.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.yko_dynamic_tile_compressor.argtypes = [vp, C.c_int, vp]
+    lib.yko_build_table.argtypes = [C.c_int, C.c_int, vp]
+    lib.yko_curve_constants.argtypes = [vp]
+    lib.yko_palette_remap.argtypes = [vp, C.c_int, C.c_int]
+    lib.yko_palette_compress.argtypes = [vp, vp, C.c_int]
+    lib.yko_last_palette.restype = vp
+    lib.yko_last_palette.argtypes = [vp, ip]
+    lib.yko_palette_decompress.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.yko_dec_create.restype = vp
+    lib.yko_dec_create.argtypes = [C.c_int, C.c_int]
+    lib.yko_dec_destroy.argtypes = [vp]
+    lib.yko_dec_gradient.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
+    lib.yko_dec_split_masks.argtypes = [vp]
+    lib.yko_dec_1d.argtypes = [vp, C.c_int, vp, ip, vp, ip, C.c_int]
+    lib.yko_dec_mask.argtypes = [vp, C.c_int, C.c_int, vp]
+    for name in ("yko_dec_planes", "yko_dec_tile4x4", "yko_dec_map_rgb", "yko_dec_map_rgb_mask"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, ip]
+    return lib
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _arr(ptr, n, dtype=np.uint8) -> np.ndarray:
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class OracleEncoder:
+    """Mirror of the EncoderContext hot-path operator surface, on the CPU oracle."""
+
+    def __init__(self, planes: np.ndarray):
+        self.planes = np.ascontiguousarray(planes, dtype=np.int32)
+        self.n, self.h, self.w = self.planes.shape
+        ptrs = (C.c_void_p * 4)(*[self.planes[i].ctypes.data if i < self.n else None for i in range(4)])
+        self._e = lib().yko_enc_create(self.w, self.h, self.n, ptrs)
+        if not self._e:
+            raise ValueError("bad geometry")
+
+    def __del__(self):
+        if getattr(self, "_e", None):
+            lib().yko_enc_destroy(self._e)
+            self._e = None
+
+    def mip_prefilter(self) -> dict:
+        rc = lib().yko_mip_prefilter(self._e)
+        if rc < 0:
+            raise ValueError("MipPrefilter recursion only defined for square power-of-two images")
+        b = np.zeros(10, dtype=np.int32)
+        lib().yko_get_bounds(self._e, b.ctypes.data)
+        n = C.c_int()
+        p = lib().yko_mip_bitmap(self._e, C.byref(n))
+        return {"has_chunk": bool(rc), "bounds": b[:4].copy(), "tile_size": int(b[4]), "remaining": int(b[5]),
+                "tile_bbox": b[6:10].copy(), "bitmap": _arr(p, n.value)}
+
+    def bounds(self) -> np.ndarray:
+        b = np.zeros(10, dtype=np.int32)
+        lib().yko_get_bounds(self._e, b.ctypes.data)
+        return b[:4].copy()
+
+    def fitting_quad_smooth(self, sx: int, sy: int, reject_factor: int = 3, plane_bit: int = 7):
+        cnt = lib().yko_fitting_quad_smooth(self._e, reject_factor, plane_bit, sx, sy)
+        n = C.c_int()
+        p = lib().yko_last_bitmap(self._e, C.byref(n)); bitmap = _arr(p, n.value)
+        p = lib().yko_last_rgb_stream(self._e, C.byref(n)); rgb = _arr(p, n.value)
+        return cnt, bitmap, rgb
+
+    def palette_compress(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        n = lib().yko_palette_compress(self._e, rgb.ctypes.data, rgb.size)
+        if n < 0:
+            raise RuntimeError("PaletteCompressor overflow")
+        c = C.c_int()
+        p = lib().yko_last_palette(self._e, C.byref(c))
+        return _arr(p, c.value)
+
+    def state(self, name: str, plane: int = 0) -> np.ndarray:
+        n = self.w * self.h
+        L = lib()
+        if name == "smoothMap":
+            return _arr(L.yko_smooth_map(self._e), n).reshape(self.h, self.w)
+        if name == "mipmapMask":
+            return _arr(L.yko_mipmap_mask(self._e), n).reshape(self.h, self.w)
+        if name == "mapSmoothTile":
+            return _arr(L.yko_map_smooth_tile(self._e, plane), n).reshape(self.h, self.w)
+        if name == "preview":
+            return _arr(L.yko_preview(self._e, plane), n, np.int32).reshape(self.h, self.w)
+        raise KeyError(name)
+
+    def dynamic_tile_encode(self, plane: int, mode3bit_only: bool, fill: int = -1):
+        dst = np.full((self.h, self.w), fill, dtype=np.int32)
+        lib().yko_dynamic_tile_encode(self._e, int(mode3bit_only), plane, dst.ctypes.data)
+        n, nn = C.c_int(), C.c_int()
+        p = lib().yko_last_tile_defs(self._e, C.byref(n)); defs = _arr(p, n.value, np.uint16)
+        p = lib().yko_last_nibbles(self._e, C.byref(n), C.byref(nn)); nib = _arr(p, n.value)
+        return defs, nib, nn.value, dst
+
+    def dynamic_tile_compressor(self, plane: int):
+        dbg = np.zeros((self.h, self.w), dtype=np.int32)
+        tiles = lib().yko_dynamic_tile_compressor(self._e, plane, dbg.ctypes.data)
+        return tiles, dbg
+
+    def streams_1d(self):
+        n = C.c_int()
+        p = lib().yko_1d_pix_stream(self._e, C.byref(n)); pix = _arr(p, n.value)
+        p = lib().yko_1d_type_stream(self._e, C.byref(n)); typ = _arr(p, n.value)
+        return pix, typ
+
+
+class OracleDecoder:
+    def __init__(self, w: int, h: int):
+        self.w, self.h = w, h
+        self._d = lib().yko_dec_create(w, h)
+
+    def __del__(self):
+        if getattr(self, "_d", None):
+            lib().yko_dec_destroy(self._d)
+            self._d = None
+
+    def gradient(self, sx: int, sy: int, bitmap: np.ndarray, rgb_dq: np.ndarray) -> int:
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        rgb_dq = np.ascontiguousarray(rgb_dq, dtype=np.uint8)
+        return lib().yko_dec_gradient(self._d, sx, sy, bitmap.ctypes.data, bitmap.size,
+                                      rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size)
+
+    def split_masks(self):
+        lib().yko_dec_split_masks(self._d)
+
+    def decode_1d(self, typ: np.ndarray, pix: np.ndarray, compression_range: int = 15):
+        typ = np.ascontiguousarray(np.concatenate([typ, np.zeros(64, np.uint8)]))
+        pix = np.ascontiguousarray(np.concatenate([pix, np.zeros(64, np.uint8)]))
+        tp, pp = C.c_int(0), C.c_int(0)
+        for p in range(3):
+            lib().yko_dec_1d(self._d, p, typ.ctypes.data, C.byref(tp), pix.ctypes.data, C.byref(pp), compression_range)
+        return tp.value, pp.value
+
+    def planes(self) -> np.ndarray:
+        n = C.c_int()
+        p = lib().yko_dec_planes(self._d, C.byref(n))
+        return _arr(p, n.value * 3).reshape(3, n.value)
+
+    def tile4x4(self) -> np.ndarray:
+        n = C.c_int()
+        p = lib().yko_dec_tile4x4(self._d, C.byref(n))
+        return _arr(p, n.value)
+
+    def map_rgb(self) -> np.ndarray:
+        n = C.c_int()
+        p = lib().yko_dec_map_rgb(self._d, C.byref(n))
+        return _arr(p, n.value)
+
+    def map_rgb_mask(self) -> np.ndarray:
+        n = C.c_int()
+        p = lib().yko_dec_map_rgb_mask(self._d, C.byref(n))
+        return _arr(p, n.value)
+
+
+def palette_remap(stream: np.ndarray, original_range: int = 250) -> np.ndarray:
+    out = np.ascontiguousarray(stream, dtype=np.uint8).copy()
+    if out.size:
+        lib().yko_palette_remap(out.ctypes.data, out.size, original_range)
+    return out
+
+
+def palette_decompress(pal: np.ndarray, out_size: int, color_compression: int = 250) -> np.ndarray:
+    buf = np.concatenate([np.ascontiguousarray(pal, dtype=np.uint8), np.zeros(128 * 3 + 8, np.uint8)])
+    out = np.zeros(out_size, dtype=np.uint8)
+    ok = lib().yko_palette_decompress(buf.ctypes.data, int(pal.size), out.ctypes.data, out_size, color_compression)
+    if not ok:
+        raise RuntimeError("PaletteDecompressor rejected the stream")
+    return out
+
+
+def detile(plane_tiled: np.ndarray, w: int, h: int) -> np.ndarray:
+    """8x8-tiled u8 plane (include/YAIK.h:205-224) -> row-major [h, w]."""
+    tw, th = (w + 7) // 8, (h + 7) // 8
+    return plane_tiled.reshape(th, tw, 8, 8).transpose(0, 2, 1, 3).reshape(th * 8, tw * 8)[:h, :w]

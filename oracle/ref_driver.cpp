@@ -1,0 +1,262 @@
+// TEST INFRASTRUCTURE ONLY (oracle/).  Never linked into, imported by or executed from the product path.
+//
+// Harness around the UNMODIFIED reference sources, which are compiled where they lie under
+// /root/reference by oracle/Makefile (outputs only into oracle/_ref/).  It feeds raw int32 planes to
+// the reference's own per-tile passes and decode loops and dumps every intermediate the parity tests
+// need as a flat list of named blobs:
+//
+//   EncoderContext::MipPrefilter          encoder/EncoderContext.cpp:1257
+//   EncoderContext::FittingQuadSmooth x7  encoder/EncoderContext.cpp:3710 (pass order :9057-9093)
+//   DynamicTileEncoderTable + EncoderContext::DynamicTileEncode   :702, :4365
+//   EncoderContext::DynamicTileCompressor                         :8398
+//   DecompressGradient16x16..4x4          decoder/YAIK_Gradient.cpp:28..1208
+//   Decompress1D                          decoder/YAIK_3DTile.cpp:24
+//
+// The reference frees its raw streams before returning, so they are captured where they cross a
+// translation-unit boundary, with the GNU linker's --wrap of ZSTD_compress (raw tile bitmaps, tile
+// definitions, nibble stream, PaletteCompressor output).  The corner-colour stream is recovered by
+// running the reference's own PaletteDecompressor on that output, exactly as the decoder does, which
+// yields the de-quantised bytes the gradient decode loops consume.  No reference code is copied or altered.
+//
+// usage: ref_driver <in.bin> <out.blobs>
+//   in.bin  : int32 w, h, nPlanes, then nPlanes planes of w*h int32 (row-major, values 0..255)
+#define protected public
+#define private public
+#include "EncoderContext.h"
+#undef protected
+#undef private
+#include "YAIK_functions.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <unistd.h>
+
+// ---- reference symbols that no header declares (EncoderContext.cpp:702, :8217-8218)
+void DynamicTileEncoderTable();
+extern u8* streamType;
+extern u8* pType;
+
+// ---- captured cross-TU calls -------------------------------------------------------------------
+struct Capture { int level; std::vector<u8> data; };
+static std::vector<Capture> gZstd;
+
+extern "C" size_t __real_ZSTD_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level);
+extern "C" size_t __wrap_ZSTD_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
+    Capture c; c.level = level;
+    c.data.assign((const u8*)src, (const u8*)src + srcSize);
+    gZstd.push_back(c);
+    // Level is irrelevant to the captured raw bytes; use a fast one so the oracle runs in seconds.
+    return __real_ZSTD_compress(dst, dstCap, src, srcSize, 1);
+}
+
+
+// ---- blob writer -------------------------------------------------------------------------------
+static FILE* gOut = NULL;
+static void blob(const std::string& name, const void* data, size_t len) {
+    u32 nl = (u32)name.size();
+    unsigned long long dl = len;
+    fwrite(&nl, 4, 1, gOut); fwrite(name.data(), 1, nl, gOut);
+    fwrite(&dl, 8, 1, gOut); if (len) fwrite(data, 1, len, gOut);
+}
+static void blobPlane8(const std::string& name, Plane* p) {          // 0 / non-zero -> 0 / 255 etc, clamp to u8
+    int n = p->GetWidth() * p->GetHeight();
+    std::vector<u8> b(n);
+    for (int i = 0; i < n; i++) b[i] = (u8)p->GetPixels()[i];
+    blob(name, b.data(), n);
+}
+static void blobPlane16(const std::string& name, Plane* p) {
+    int n = p->GetWidth() * p->GetHeight();
+    std::vector<short> b(n);
+    for (int i = 0; i < n; i++) b[i] = (short)p->GetPixels()[i];
+    blob(name, b.data(), n * 2);
+}
+static std::string nm(const char* base, int a, int b = -1) {
+    char buf[128];
+    if (b >= 0) snprintf(buf, sizeof buf, "%s_%d_%d", base, a, b); else snprintf(buf, sizeof buf, "%s_%d", base, a);
+    return buf;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: ref_driver in.bin out.blobs\n"); return 2; }
+    FILE* fi = fopen(argv[1], "rb");
+    if (!fi) { perror("in"); return 2; }
+    int hdr[3];
+    if (fread(hdr, 4, 3, fi) != 3) return 2;
+    int w = hdr[0], h = hdr[1], np = hdr[2];
+    Image* img = Image::CreateImage(w, h, np, false);
+    for (int p = 0; p < np; p++) {
+        if (fread(img->GetPlane(p)->GetPixels(), 4, (size_t)w * h, fi) != (size_t)w * h) return 2;
+    }
+    fclose(fi);
+    gOut = fopen(argv[2], "wb");
+    if (!gOut) { perror("out"); return 2; }
+
+    // The passes printf per tile (EncoderContext.cpp:4216, :8507); silence them.
+    if (!freopen("/dev/null", "w", stdout)) return 2;
+
+    char tmpl[] = "/tmp/yaikrefXXXXXX";
+    char* dir = mkdtemp(tmpl);
+    if (!dir || chdir(dir) != 0) return 2;          // debug PNGs the passes write land here
+
+    EncoderContext* ctx = new EncoderContext();
+    ctx->evaluateLUT = false; ctx->evaluateLUT2D = false; ctx->dumpImage = false; ctx->pStats = NULL;
+    ctx->mapSmoothTile = NULL; ctx->mappedRGB = NULL;
+    ctx->SetImageToEncode(img);
+    ctx->outFile = fopen("chunks.bin", "wb+");
+    ctx->fileOutSize = 0;
+
+    int meta[3] = { w, h, np };
+    blob("meta", meta, sizeof meta);
+
+    // ---- a9 alpha tile-reject ----
+    if (np == 4) {
+        long before = ftell(ctx->outFile);
+        ctx->MipPrefilter(true);
+        fflush(ctx->outFile);
+        long after = ftell(ctx->outFile);
+        std::vector<u8> chunk(after - before);
+        fseek(ctx->outFile, before, SEEK_SET);
+        if (!chunk.empty() && fread(chunk.data(), 1, chunk.size(), ctx->outFile) != chunk.size()) return 2;
+        fseek(ctx->outFile, after, SEEK_SET);
+        blob("mip_chunk", chunk.data(), chunk.size());
+        int b[6] = { ctx->boundX0, ctx->boundY0, ctx->boundX1, ctx->boundY1, ctx->mipMapTileSize, ctx->remainingPixels };
+        blob("mip_bounds", b, sizeof b);
+        blobPlane8("mip_mask", ctx->mipmapMask);
+    }
+
+    // ---- a6 gradient fit, 7 passes in the shipped order ----
+    static const int passes[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    Image* preview = Image::CreateImage(w, h, 3, true);
+    std::vector<std::vector<u8>> bitmaps(7), rgbdq(7);
+    int counts[7];
+    for (int i = 0; i < 7; i++) {
+        gZstd.clear();
+        fflush(ctx->outFile);
+        long before = ftell(ctx->outFile);
+        counts[i] = ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), preview, false, passes[i][0], passes[i][1]);
+        if (!gZstd.empty()) bitmaps[i] = gZstd[0].data;          // first ZSTD_compress of the pass = raw tile bitmap (:4266)
+        else {
+            // No tile accepted: the pass writes no chunk (:4239); its bitmap is all zero by construction (:3777).
+            u32 bx, by, bc; HeaderGradientTile::getSwizzleSize(passes[i][0], passes[i][1], bx, by, bc);
+            bitmaps[i].assign((((w + bx - 1) / bx) * ((h + by - 1) / by) * bc) >> 3, 0);
+        }
+        if (gZstd.size() >= 2) {
+            // second ZSTD_compress of the pass = PaletteCompressor output (:4301). Expand it with the reference's own
+            // PaletteDecompressor exactly as the decoder does (decoder/YAIK_API.cpp:896-910): padded input, sizes from the header.
+            fflush(ctx->outFile);
+            long after = ftell(ctx->outFile);
+            fseek(ctx->outFile, before, SEEK_SET);
+            HeaderBase hb; HeaderGradientTile hg;
+            if (fread(&hb, sizeof hb, 1, ctx->outFile) != 1 || fread(&hg, sizeof hg, 1, ctx->outFile) != 1) return 2;
+            fseek(ctx->outFile, after, SEEK_SET);
+            std::vector<u8> pal(gZstd[1].data); size_t palSize = pal.size(); pal.resize(palSize + 128 * 3, 0);
+            rgbdq[i].assign(hg.streamRGBSizeUncompressed, 0);
+            bool ok = PaletteDecompressor(pal.data(), (int)palSize, (int)palSize + 128 * 3, rgbdq[i].data(), (int)hg.streamRGBSizeUncompressed, hg.colorCompression);
+            if (!ok) { fprintf(stderr, "PaletteDecompressor failed pass %d\n", i); return 3; }
+            blob(nm("grad_palette", i), gZstd[1].data.data(), gZstd[1].data.size());
+        }
+        blob(nm("grad_bitmap", i), bitmaps[i].data(), bitmaps[i].size());
+        blob(nm("grad_rgbdq", i), rgbdq[i].data(), rgbdq[i].size());
+    }
+    blob("grad_counts", counts, sizeof counts);
+    blobPlane8("smoothMap", ctx->smoothMap);
+    blobPlane8("mipmapMask_post", ctx->mipmapMask);
+    for (int p = 0; p < 3; p++) {
+        blobPlane8(nm("mapSmoothTile", p), ctx->mapSmoothTile->GetPlane(p));
+        blobPlane16(nm("preview", p), preview->GetPlane(p));
+    }
+    int bnd[4] = { ctx->boundX0, ctx->boundY0, ctx->boundX1, ctx->boundY1 };
+    blob("bounds_post", bnd, sizeof bnd);
+
+    // ---- a10-a13 range quantiser, both start modes (0 = 4-bpp allowed, 3 = 3-bpp only) ----
+    DynamicTileEncoderTable();
+    for (int m = 0; m < 2; m++) {
+        for (int p = 0; p < 3; p++) {
+            Plane* dst = new Plane(w, h);
+            BoundingBox full = dst->GetRect();
+            dst->Fill(full, -1);
+            gZstd.clear();
+            ctx->DynamicTileEncode(m == 1, img->GetPlane(p), dst, false, false, false, false);
+            // :4519 tile definitions, :4533 nibble index stream
+            blob(nm("plnt_defs", m, p), gZstd[0].data.data(), gZstd[0].data.size());
+            blob(nm("plnt_idx", m, p), gZstd[1].data.data(), gZstd[1].data.size());
+            blobPlane16(nm("plnt_dst", m, p), dst);
+            delete dst;
+        }
+    }
+
+    // ---- a15 live 1-D range path ----
+    size_t cap = (size_t)w * h * 3 + 64;
+    std::vector<u8> pix(cap), types((size_t)(w / 8) * (h / 8) * 9 + 64);
+    streamType = types.data(); pType = types.data();       // the reference's own 100000-byte global overflows beyond ~512x512
+    u8* wr = pix.data();
+    int ends[6];
+    Image* out1d = Image::CreateImage(w, h, 3, true);
+    for (int p = 0; p < 3; p++) {
+        wr = ctx->DynamicTileCompressor(wr, img->GetPlane(p), ctx->mapSmoothTile->GetPlane(p), out1d->GetPlane(p));
+        ends[p] = (int)(wr - pix.data());
+        ends[3 + p] = (int)(pType - types.data());
+    }
+    blob("d1_pix", pix.data(), ends[2]);
+    blob("d1_type", types.data(), ends[5]);
+    blob("d1_ends", ends, sizeof ends);
+    for (int p = 0; p < 3; p++) blobPlane16(nm("d1_out", p), out1d->GetPlane(p));
+
+    // ---- a16/a17 decode loops on a hand-filled YAIK_Instance (allocation rule: decoder/YAIK_API.cpp:650-657, :855-874) ----
+    YAIK_Instance inst; memset(&inst, 0, sizeof inst);
+    inst.width = (u16)w; inst.height = (u16)h;
+    inst.tileWidth = (u16)((w + 7) >> 3); inst.tileHeight = (u16)((h + 7) >> 3);
+    int planeSize = inst.tileWidth * inst.tileHeight * 64;
+    std::vector<u8> planes((size_t)planeSize * 3, 0);
+    inst.planeR = planes.data(); inst.planeG = inst.planeR + planeSize; inst.planeB = inst.planeG + planeSize;
+    inst.strideRGBMap = (u16)((w >> 2) + 1);
+    int latt = inst.strideRGBMap * ((h >> 2) + 1);
+    std::vector<u8> mapRGB((size_t)latt * 3, 0);
+    int sizeMask = (latt + 7) >> 3;
+    std::vector<u8> mapMask((size_t)sizeMask * 3, 0);
+    inst.mapRGB = mapRGB.data(); inst.mapRGBMask = mapMask.data(); inst.sizeMapMask = sizeMask;
+    inst.tile4x4MaskSize = ((((w + 15) >> 4) << 2) * (((h + 7) >> 3) << 1)) >> 3;
+    std::vector<u8> t4((size_t)inst.tile4x4MaskSize * 3, 0);
+    inst.tile4x4Mask = t4.data(); inst.singleRGB = true;
+
+    typedef void (*GradFn)(YAIK_Instance*, u8*, u8*, u8*, u8*, u8*, u8);
+    GradFn fns[7] = { DecompressGradient16x16, DecompressGradient16x8, DecompressGradient8x16, DecompressGradient8x8,
+                      DecompressGradient8x4, DecompressGradient4x8, DecompressGradient4x4 };
+    size_t slack = (size_t)((w + 3) >> 2) * ((h + 3) >> 2) * 12;     // "secure buffer" of YAIK_API.cpp:901
+    for (int i = 0; i < 7; i++) {
+        if (counts[i] == 0) continue;
+        std::vector<u8> rgb(rgbdq[i]); rgb.resize(rgb.size() + slack, 0);
+        std::vector<u8> bm(bitmaps[i]);
+        fns[i](&inst, bm.data(), rgb.data(), inst.planeR, inst.planeG, inst.planeB, 7);
+    }
+    blob("dec_planes_grad", planes.data(), planes.size());
+    blob("dec_tile4x4", t4.data(), inst.tile4x4MaskSize);
+    blob("dec_mapRGB", mapRGB.data(), mapRGB.size());
+    blob("dec_mapRGBMask", mapMask.data(), sizeMask);
+
+    // transition single -> per-plane masks (YAIK_API.cpp:530-544), then the three Decompress1D calls (:985-991)
+    for (int p = 1; p < 3; p++) {
+        memcpy(&mapMask[(size_t)sizeMask * p], mapMask.data(), sizeMask);
+        memcpy(&t4[(size_t)inst.tile4x4MaskSize * p], t4.data(), inst.tile4x4MaskSize);
+    }
+    inst.singleRGB = false;
+    Header1D h1; memset(&h1, 0, sizeof h1);
+    h1.compressionColor = (u8)ctx->colorCompression1D; h1.compressionRange = (u8)ctx->rangeCompression1D;
+    std::vector<u8> pixPad(pix.begin(), pix.begin() + ends[2]); pixPad.resize(pixPad.size() + 64, 0);
+    std::vector<u8> typPad(types.begin(), types.begin() + ends[5]); typPad.resize(typPad.size() + 64, 0);
+    u8* tp = typPad.data(); u8* pp = pixPad.data();
+    for (int p = 0; p < 3; p++) Decompress1D(&inst, &tp, &pp, (u8)p, &h1);
+    int consumed[2] = { (int)(tp - typPad.data()), (int)(pp - pixPad.data()) };
+    blob("dec_1d_consumed", consumed, sizeof consumed);
+    blob("dec_planes_full", planes.data(), planes.size());
+
+    fclose(gOut);
+    fclose(ctx->outFile);
+    // leave the scratch dir clean
+    if (system("rm -f ./*.png ./EncoderDebug* chunks.bin") != 0) {}
+    if (chdir("/") == 0) rmdir(dir);
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""Deterministic synthetic input "YAIK-synth v1" (SURVEY.md §8d).
+
+Planar int32 planes with values in [0, 255], laid out exactly like the reference's ``Plane``
+(row-major, ``idx = x + y*w``; encoder/framework.h:82).  Used by the tests, the golden-vector
+generator and bench.py so that the CPU baseline and the GPU path see identical pixels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_A = 1664525
+_C = 1013904223
+_MASK = 0xFFFFFFFF
+
+
+def _lcg_stream(n: int, seed: int) -> np.ndarray:
+    """s_k = LCG^(k+1)(seed) for k in [0, n) as uint32, via jump-ahead tables (no Python loop per pixel)."""
+    chunk = 1 << 16
+    # per-offset multipliers/increments inside a chunk: s_{j} = A[j]*s0 + Cc[j]  (mod 2^32), j = 1..chunk
+    A = np.empty(chunk, dtype=np.uint64)
+    Cc = np.empty(chunk, dtype=np.uint64)
+    A[0] = _A
+    Cc[0] = _C
+    filled = 1
+    while filled < chunk:
+        take = min(filled, chunk - filled)
+        aL = A[filled - 1]
+        cL = Cc[filled - 1]
+        A[filled:filled + take] = (A[:take] * aL) & _MASK
+        Cc[filled:filled + take] = (Cc[:take] * aL + cL) & _MASK
+        filled += take
+    out = np.empty(n, dtype=np.uint32)
+    s0 = np.uint64(seed & _MASK)
+    pos = 0
+    while pos < n:
+        m = min(chunk, n - pos)
+        vals = (A[:m] * s0 + Cc[:m]) & _MASK
+        out[pos:pos + m] = vals.astype(np.uint32)
+        s0 = vals[m - 1]
+        pos += m
+    return out
+
+
+def synth_planes(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12345) -> np.ndarray:
+    """Return an int32 array [n_planes, h, w] (R, G, B[, A]).  ``w`` is the ramp/class scale (square rule of §8d)."""
+    if h is None:
+        h = w
+    W = w
+    s = _lcg_stream(w * h, seed).reshape(h, w)
+    y, x = np.meshgrid(np.arange(h, dtype=np.int64), np.arange(w, dtype=np.int64), indexing="ij")
+    k = ((x >> 6) + (y >> 6)) & 3
+    r = (255 * x) // W
+    g = np.minimum((255 * y) // W, 255)
+    b = np.minimum((255 * (x + y)) // (2 * W), 255)
+    s64 = s.astype(np.int64)
+    n2 = np.stack([(s64 >> 8) & 7, (s64 >> 12) & 7, (s64 >> 16) & 7])
+    n3 = np.stack([(s64 >> 8) & 255, (s64 >> 16) & 255, (s64 >> 24) & 255])
+    base = np.stack([r, g, b])
+    rgb = np.where(k == 2, (base + n2) % 256, base)
+    rgb = np.where(k == 3, n3, rgb)
+    planes = [rgb[0], rgb[1], rgb[2]]
+    if n_planes == 4:
+        frame = (x < W // 8) | (x >= W - W // 16) | (y < W // 16) | (y >= W - W // 8)
+        holes = (((x >> 7) + (y >> 7)) % 5) == 0
+        planes.append(np.where(frame | holes, 0, 255))
+    return np.ascontiguousarray(np.stack(planes).astype(np.int32))
