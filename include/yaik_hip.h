@@ -1,0 +1,148 @@
+/* yaik_hip.h — C-ABI of the MI355X (gfx950) implementation of the YAIK per-tile hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handle, caller-owned pointers and sizes, no C++ or
+ * torch types.  Every entry point names the reference interface it replaces (paths relative to the
+ * KLab/YAIK tree).  The reference has no FFI of its own — the passes are C++ member functions called
+ * in-process — so the boundary sits exactly where `EncoderContext` touches pixels; the C++ mirror of
+ * that class in yaik_amd/host/ (same method names and argument meaning) is a thin caller of these
+ * functions, and INTEGRATION.md shows the binding a YAIK maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative yk_status on failure (first error text is kept
+ *     in the handle: yk_last_error).  Nothing throws.  There is NO CPU fallback: without a usable
+ *     HIP device yk_create fails.
+ *   - one handle per host thread / GPU; handles are not thread-safe.
+ *   - "device pointer" = HBM address valid on the handle's device (e.g. torch tensor data_ptr()).
+ *   - planes are int32, row-major, values in [0,255]: the reference `Plane` layout
+ *     (encoder/framework.h:74-127, idx = x + y*w).  Width and height must be multiples of 8
+ *     (Image::LoadPNG enforces the same, encoder/Image.cpp:206).
+ *   - all launches go to the handle's stream; getters that copy to host synchronise that stream.
+ */
+#ifndef YAIK_HIP_H
+#define YAIK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yk_ctx yk_ctx;
+
+enum yk_status {
+    YK_OK = 0,
+    YK_ERR_NO_DEVICE = -1,      /* no HIP device / runtime: the product path refuses to run */
+    YK_ERR_BAD_ARG = -2,
+    YK_ERR_HIP = -3,            /* a HIP call failed; see yk_last_error */
+    YK_ERR_STATE = -4,          /* call order violated (e.g. encode before binding planes) */
+    YK_ERR_RANGE = -5           /* output buffer too small */
+};
+
+/* number of gradient passes and their (tileShiftX, tileShiftY) in the shipped order
+ * 16x16,16x8,8x16,8x8,8x4,4x8,4x4 (encoder/EncoderContext.cpp:9057-9093) */
+#define YK_NUM_PASSES 7
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int         yk_create(int device, yk_ctx** out);
+void        yk_destroy(yk_ctx* c);
+const char* yk_last_error(const yk_ctx* c);
+int         yk_set_stream(yk_ctx* c, void* hipStream);      /* NULL = the handle's own stream */
+int         yk_synchronize(yk_ctx* c);
+int         yk_device_count(void);                          /* no device initialisation side effects beyond hipGetDeviceCount */
+
+/* ---- image binding:  EncoderContext::SetImageToEncode (encoder/EncoderContext.cpp:1227) ------
+ * A handle works on one image or one row stripe of an image.  fullW/fullH are the whole image,
+ * [y0, y0+h) the rows this handle owns (y0 and h multiples of 64 unless the stripe is the last one);
+ * for a whole image pass y0 = 0, h = fullH.  The planes handed in must contain the owned rows plus
+ * `haloRows` (0 or 1) further row: FittingQuadSmooth samples the BL/BR corners at y+T
+ * (EncoderContext.cpp:3855-3856); the last stripe clamps like Plane::GetPixelValue instead. */
+int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, int haloRows);
+/* host planes -> HBM copy owned by the handle (strideElems = row pitch in int32 elements) */
+int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideElems);
+/* zero-copy: planes already resident in HBM */
+int yk_bind_device_planes(yk_ctx* c, const int32_t* const devPlanes[4], int strideElems);
+
+/* ---- a9  alpha tile-reject:  EncoderContext::MipPrefilter (EncoderContext.cpp:1257-1427) -----
+ * stage 1 (per stripe): per aligned 16x16 block "all 256 alphas == 0" + bounding box of kept blocks. */
+int yk_alpha_reject(yk_ctx* c);
+/* bbox of kept blocks of THIS stripe in full-image pixels {x0,y0,x1,y1}; {9999999,9999999,-1,-1} if none. Synchronises. */
+int yk_get_stripe_bbox(yk_ctx* c, int32_t bbox[4]);
+/* stage 2: the image-wide bbox (min/max over stripes; for a whole image pass yk_get_stripe_bbox's result or NULL
+ * to use the handle's own).  Applies the reference rule "bbox == whole image -> all rejects discarded, no chunk"
+ * (:1294, :1400-1403) and fixes boundX0..Y1 for the range quantiser.  Images without alpha: call with NULL or skip. */
+int yk_alpha_finish(yk_ctx* c, const int32_t globalBBox[4]);
+/* results: bounds[4] = boundX0,boundY0,boundX1,boundY1; hasChunk; remainingPixels (this stripe);
+ * tileBBox[4] = MipmapHeader.bbox in 16-px tiles (x,y,w,h).  Synchronises. */
+int yk_alpha_result(yk_ctx* c, int32_t bounds[4], int* hasChunk, int* remainingPixels, int32_t tileBBox[4]);
+/* 'MIPM' payload: 1 bit per 16x16 tile inside tileBBox, row-major, LSB first, 1 = kept (:1317-1327).
+ * For a stripe: only the bits of the owned rows are set (OR the stripes' buffers). cap >= (w*h+7)/8 of tileBBox. */
+int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
+
+/* ---- a6 + a10..a13  fused tile encode ----------------------------------------------------------
+ * One launch does what 7x EncoderContext::FittingQuadSmooth(rejectFactor, R,G,B, .., sx, sy)
+ * (EncoderContext.cpp:3710-4363) followed by DynamicTileEncode(mode3BitOnly, plane, dst, ..) for the three
+ * planes (EncoderContext.cpp:4365-4602) compute, reading every input sample once.
+ *   rejectFactor : the reference passes 3 (:9042)
+ *   mode3BitOnly : DynamicTileEncode's first argument (Stats.startMode = 3, :4412)
+ *   wantDst      : also produce the decoded-value planes `dst` (:4448-4457); costs 12 B/pixel of writes */
+int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
+
+/* gradient results (valid after yk_encode_tiles) -------------------------------------------------
+ * swizzled 1-bit tile bitmap of pass p, byte-exact `pFillBitMap` (:3775-3777, bit rule :3801-3805,:4026;
+ * size = HeaderGradientTile::getBitmapSwizzleSize/8, include/YAIK_private.h:278-286) */
+size_t yk_gradient_bitmap_bytes(const yk_ctx* c, int pass);
+int    yk_gradient_bitmap(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap);
+const uint8_t* yk_gradient_bitmap_device(const yk_ctx* c, int pass);
+/* accepted-tile count per pass = FittingQuadSmooth's return value (TileDone, :4362). Synchronises. */
+int    yk_gradient_counts(yk_ctx* c, int32_t counts[YK_NUM_PASSES]);
+/* coverage after the 7 passes: 1 bit per 4x4 cell, u16 per 16x16 macro-tile (bit = cellY*4+cellX), row-major
+ * macro-tiles.  Equals smoothMap/mapSmoothTile != 0 sampled per cell (:4029-4037). */
+int    yk_coverage(yk_ctx* c, uint16_t* hostOut, size_t capElems);
+/* corner-colour stream of pass p = `rgbStream` (:4113-4132): CompressF(Round6(corner),250) bytes of every corner
+ * not yet in `mappedRGB`, in scan order, de-duplicated across passes.  Call for p = 0..6 in order. */
+int    yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap, size_t* nBytes);
+
+/* range-quantiser results per plane (valid after yk_encode_tiles) ---------------------------------
+ * tileDefs = `streamTileDef` u16 EncodeTileType(type,range,base) of tiles with >= 1 valid pixel, LeftRightOrder
+ * (:4419,:4434-4438); nibbles = `streamTileIdx`, low nibble first (:1180-1184), closed to a whole byte (:4525). */
+int yk_range_sizes(yk_ctx* c, int plane, size_t* nDefs, size_t* nNibbles);        /* synchronises */
+int yk_range_streams(yk_ctx* c, int plane, uint16_t* hostDefs, size_t capDefs, uint8_t* hostNibbles, size_t capBytes);
+const uint16_t* yk_range_defs_device(const yk_ctx* c, int plane);
+const uint8_t*  yk_range_nibbles_device(const yk_ctx* c, int plane);
+/* `dst` plane (int32 w*h of this stripe; untouched where no valid pixel; pre-filled with `fill`) */
+int yk_range_dst(yk_ctx* c, int plane, int32_t* hostOut, size_t capElems);
+int yk_set_dst_fill(yk_ctx* c, int32_t fill);
+
+/* ---- tile-map export for the multi-GPU gather (new; the reference is single-process) -----------------------
+ * Packs this handle's results into ONE caller-owned HBM buffer (device-to-device copies on the handle's stream) so
+ * that a single RCCL gather can concatenate the per-stripe / per-frame tile maps.  Layout, every section padded to
+ * 16 bytes: 7 gradient bitmaps | keep flags (1 byte per 16x16 tile, RGBA only) | per plane: tile defs (u16), nibbles.
+ * sizes[0..6] bitmap bytes, sizes[7] keep bytes, sizes[8+2p] = nDefs(p), sizes[9+2p] = nNibbles(p), sizes[14] = total
+ * bytes written.  Synchronises (the stream sizes live on the device).  cap: see yk_export_capacity. */
+size_t yk_export_capacity(const yk_ctx* c);
+int    yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]);
+
+/* ---- decode side: the loops behind YAIK_DecodeImage's chunk switch (decoder/YAIK_API.cpp:731-1303) ----
+ * Buffers mirror YAIK_Instance (include/YAIK_private.h:26-54): planeR/G/B u8 in 8x8 tiles, mapRGB lattice,
+ * tile4x4Mask.  Width/height multiples of 16 (the reference loops mis-stride otherwise, YAIK_Gradient.cpp:15). */
+int yk_decode_begin(yk_ctx* c, int w, int h);
+/* DecompressGradient16x16 .. 4x4 (decoder/YAIK_Gradient.cpp:28,203,401,599,800,999,1208), planeBit 7.
+ * bitmap = swizzled tile bitmap, rgb = corner stream AFTER PaletteDecompressor (0..255). Host pointers. */
+int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* bitmap, size_t bitmapBytes,
+                       const uint8_t* rgb, size_t rgbBytes);
+/* Decompress1D x3 planes (decoder/YAIK_3DTile.cpp:24-240) on the '1DTL' streams (type: 3 B/tile, pix: 1 B/pixel) */
+int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes,
+                 int compressionRange);
+/* Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154): 1 bit / 16x16 tile -> swizzled 1 bit / pixel mask */
+int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int tileBBoxW, int tileBBoxH, uint8_t* hostOut, size_t cap);
+/* 8x8-tiled u8 planes exactly as YAIK_SCustomDataSource hands them to imageBuilderFunc (include/YAIK.h:205-224) */
+int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, size_t capEach);
+const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
+int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
+
+/* ---- timing hooks for bench.py: HIP events on the handle's stream around the last yk_encode_tiles ---- */
+int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAIK_HIP_H */

@@ -1,0 +1,90 @@
+"""Loader of the in-tree HIP shared library (yaik_amd/libyaik_hip.so) and its ctypes signatures.
+
+The product path has no CPU fallback: if the library is missing, or no HIP device is usable,
+callers get a loud YaikError.  The symbol list below is checked against include/yaik_hip.h by
+tests/test_host_logic.py (no GPU needed to load the library and resolve symbols).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libyaik_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+
+class YaikError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the library (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", CSRC], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+vp, ip = C.c_void_p, C.POINTER(C.c_int)
+sz, szp = C.c_size_t, C.POINTER(C.c_size_t)
+i32p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every exported symbol of include/yaik_hip.h
+SIGNATURES = {
+    "yk_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "yk_destroy": (None, [vp]),
+    "yk_last_error": (C.c_char_p, [vp]),
+    "yk_set_stream": (C.c_int, [vp, vp]),
+    "yk_synchronize": (C.c_int, [vp]),
+    "yk_device_count": (C.c_int, []),
+    "yk_set_image": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "yk_upload_planes": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
+    "yk_bind_device_planes": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
+    "yk_alpha_reject": (C.c_int, [vp]),
+    "yk_get_stripe_bbox": (C.c_int, [vp, vp]),
+    "yk_alpha_finish": (C.c_int, [vp, vp]),
+    "yk_alpha_result": (C.c_int, [vp, vp, ip, ip, vp]),
+    "yk_alpha_bitmap": (C.c_int, [vp, vp, sz, szp]),
+    "yk_encode_tiles": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "yk_gradient_bitmap_bytes": (sz, [vp, C.c_int]),
+    "yk_gradient_bitmap": (C.c_int, [vp, C.c_int, vp, sz]),
+    "yk_gradient_bitmap_device": (vp, [vp, C.c_int]),
+    "yk_gradient_counts": (C.c_int, [vp, vp]),
+    "yk_coverage": (C.c_int, [vp, vp, sz]),
+    "yk_gradient_corners": (C.c_int, [vp, C.c_int, vp, sz, szp]),
+    "yk_range_sizes": (C.c_int, [vp, C.c_int, szp, szp]),
+    "yk_range_streams": (C.c_int, [vp, C.c_int, vp, sz, vp, sz]),
+    "yk_range_defs_device": (vp, [vp, C.c_int]),
+    "yk_range_nibbles_device": (vp, [vp, C.c_int]),
+    "yk_range_dst": (C.c_int, [vp, C.c_int, vp, sz]),
+    "yk_set_dst_fill": (C.c_int, [vp, C.c_int32]),
+    "yk_export_capacity": (sz, [vp]),
+    "yk_export_tile_maps": (C.c_int, [vp, vp, sz, vp]),
+    "yk_decode_begin": (C.c_int, [vp, C.c_int, C.c_int]),
+    "yk_decode_gradient": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz]),
+    "yk_decode_1d": (C.c_int, [vp, vp, sz, vp, sz, C.c_int]),
+    "yk_decode_mask": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, sz]),
+    "yk_decode_planes": (C.c_int, [vp, vp, vp, vp, sz]),
+    "yk_decode_planes_device": (vp, [vp, szp]),
+    "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
+    "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YaikError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback for the product path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,403 @@
+// yk_api.hip — the C-ABI of include/yaik_hip.h: handle lifetime, HBM buffers, launch order, result getters.
+// Host-side glue only; every pixel is touched by the kernels in yk_encode.hip / yk_corners.hip / yk_decode.hip.
+#include "yk_common.h"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e) {
+    if (c && c->err.empty()) {
+        c->err = what ? what : "error";
+        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+static void yk_free_image(yk_ctx* c) {
+    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    F(c->keep); F(c->bounds);
+    for (int i = 0; i < 7; i++) F(c->bitmap[i]);
+    F(c->coverage); F(c->tileDef); F(c->tileCount); F(c->slots);
+    for (int i = 0; i < 3; i++) F(c->dst[i]);
+    F(c->blockSums); F(c->totals); F(c->defsOut); F(c->nibOut);
+    F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch);
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+}
+
+extern "C" {
+
+int yk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int yk_create(int device, yk_ctx** out) {
+    if (!out) return YK_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return YK_ERR_NO_DEVICE;      // no CPU fallback, by design
+    if (device < 0 || device >= n) return YK_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return YK_ERR_NO_DEVICE;
+    yk_ctx* c = new yk_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return YK_ERR_HIP; }
+    c->stream = c->ownStream;
+    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
+    *out = c;
+    return YK_OK;
+}
+
+void yk_destroy(yk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    yk_free_image(c);
+    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch);
+    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char* yk_last_error(const yk_ctx* c) { return c ? c->err.c_str() : "null handle"; }
+
+int yk_set_stream(yk_ctx* c, void* s) {
+    if (!c) return YK_ERR_BAD_ARG;
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return YK_OK;
+}
+
+int yk_synchronize(yk_ctx* c) {
+    if (!c) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, int haloRows) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (fullW < 8 || fullH < 8 || (fullW & 7) || (fullH & 7) || fullW > 32760 || fullH > 32760) return yk_fail(c, YK_ERR_BAD_ARG, "image size must be a multiple of 8 and fit s16 fields");
+    if (nPlanes != 3 && nPlanes != 4) return yk_fail(c, YK_ERR_BAD_ARG, "nPlanes must be 3 or 4");
+    if (y0 < 0 || h < 8 || (h & 7) || y0 + h > fullH || (y0 & 63)) return yk_fail(c, YK_ERR_BAD_ARG, "stripe rows must start on a multiple of 64 and lie inside the image");
+    if (y0 + h < fullH && ((h & 63) || haloRows != 1)) return yk_fail(c, YK_ERR_BAD_ARG, "inner stripes need h % 64 == 0 and one halo row");
+    if (y0 + h == fullH && haloRows != 0) return yk_fail(c, YK_ERR_BAD_ARG, "the last stripe has no halo row");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (c->fullW == fullW && c->fullH == fullH && c->nPlanes == nPlanes && c->y0 == y0 && c->h == h && c->halo == haloRows && c->tileCount) {
+        c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+        return YK_OK;
+    }
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    yk_free_image(c);
+    c->fullW = fullW; c->fullH = fullH; c->nPlanes = nPlanes; c->y0 = y0; c->h = h; c->halo = haloRows;
+    c->tilesW = fullW / 8; c->tilesH = h / 8; c->mtW = (fullW + 15) / 16; c->mtH = (h + 15) / 16;
+    const size_t T8 = (size_t)c->tilesW * c->tilesH, MT = (size_t)c->mtW * c->mtH;
+    YK_HIP(c, hipMalloc(&c->keep, MT));
+    YK_HIP(c, hipMalloc(&c->bounds, 16 * sizeof(int32_t)));
+    static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    for (int i = 0; i < 7; i++) {
+        const int bx = (sh[i][0] == 2) ? 32 : 64, by = (sh[i][1] == 2) ? 32 : 64;
+        const size_t bits = (size_t)((fullW + bx - 1) / bx) * ((h + by - 1) / by) * ((bx >> sh[i][0]) * (by >> sh[i][1]));
+        c->bitmapBytes[i] = bits >> 3;
+        YK_HIP(c, hipMalloc(&c->bitmap[i], c->bitmapBytes[i] + 16));
+    }
+    YK_HIP(c, hipMalloc(&c->coverage, MT * sizeof(uint16_t)));
+    YK_HIP(c, hipMalloc(&c->tileDef, 3 * T8 * sizeof(uint16_t)));
+    YK_HIP(c, hipMalloc(&c->tileCount, 3 * T8));
+    YK_HIP(c, hipMalloc(&c->slots, 3 * T8 * YK_SLOT));
+    c->nScanBlocks = (int)((T8 + 1023) / 1024);
+    YK_HIP(c, hipMalloc(&c->blockSums, (size_t)3 * c->nScanBlocks * 2 * sizeof(uint32_t)));
+    YK_HIP(c, hipMalloc(&c->totals, 6 * sizeof(uint32_t)));
+    YK_HIP(c, hipMalloc(&c->defsOut, 3 * T8 * sizeof(uint16_t)));
+    c->nibStride = T8 * YK_SLOT + 64;
+    YK_HIP(c, hipMalloc(&c->nibOut, 3 * c->nibStride));
+    c->dstValid = false;
+    return YK_OK;
+}
+
+static int yk_check_planes(yk_ctx* c, const int32_t* const p[4], int strideElems) {
+    if (!c || !p) return YK_ERR_BAD_ARG;
+    if (!c->tileCount) return yk_fail(c, YK_ERR_STATE, "yk_set_image first");
+    if (strideElems < c->fullW || (strideElems & 3)) return yk_fail(c, YK_ERR_BAD_ARG, "row pitch must be >= width and a multiple of 4 elements");
+    for (int i = 0; i < c->nPlanes; i++) if (!p[i]) return yk_fail(c, YK_ERR_BAD_ARG, "null plane");
+    return YK_OK;
+}
+
+int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideElems) {
+    int rc = yk_check_planes(c, hostPlanes, strideElems); if (rc) return rc;
+    YK_HIP(c, hipSetDevice(c->device));
+    const size_t rows = (size_t)c->h + c->halo, planeBytes = rows * c->fullW * sizeof(int32_t);
+    if (c->ownedPlanesBytes < planeBytes * c->nPlanes) {
+        if (c->ownedPlanes) { YK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->ownedPlanes); c->ownedPlanes = nullptr; }
+        YK_HIP(c, hipMalloc(&c->ownedPlanes, planeBytes * c->nPlanes));
+        c->ownedPlanesBytes = planeBytes * c->nPlanes;
+    }
+    for (int i = 0; i < c->nPlanes; i++) {
+        int32_t* d = c->ownedPlanes + (size_t)i * rows * c->fullW;
+        YK_HIP(c, hipMemcpy2DAsync(d, (size_t)c->fullW * 4, hostPlanes[i], (size_t)strideElems * 4, (size_t)c->fullW * 4, rows, hipMemcpyHostToDevice, c->stream));
+        c->plane[i] = d;
+    }
+    c->strideElems = c->fullW;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+    return YK_OK;
+}
+
+int yk_bind_device_planes(yk_ctx* c, const int32_t* const devPlanes[4], int strideElems) {
+    int rc = yk_check_planes(c, devPlanes, strideElems); if (rc) return rc;
+    for (int i = 0; i < c->nPlanes; i++) {
+        if (((uintptr_t)devPlanes[i]) & 15) return yk_fail(c, YK_ERR_BAD_ARG, "device planes must be 16-byte aligned");
+        c->plane[i] = devPlanes[i];
+    }
+    c->strideElems = strideElems;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+    return YK_OK;
+}
+
+// ---- alpha -----------------------------------------------------------------------------------------
+int yk_alpha_reject(yk_ctx* c) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
+    if (c->nPlanes != 4) return yk_fail(c, YK_ERR_STATE, "image has no alpha plane");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    int rc = yk_launch_alpha(c); if (rc) return rc;
+    YK_HIP(c, hipEventRecord(c->ev[1], c->stream));
+    c->alphaDone = true; c->alphaFinished = false;
+    return YK_OK;
+}
+
+int yk_get_stripe_bbox(yk_ctx* c, int32_t bbox[4]) {
+    if (!c || !bbox) return YK_ERR_BAD_ARG;
+    if (!c->alphaDone) return yk_fail(c, YK_ERR_STATE, "yk_alpha_reject first");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(bbox, c->bounds + 8, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_alpha_finish(yk_ctx* c, const int32_t globalBBox[4]) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (c->nPlanes != 4) return YK_OK;
+    if (!c->alphaDone) return yk_fail(c, YK_ERR_STATE, "yk_alpha_reject first");
+    YK_HIP(c, hipSetDevice(c->device));
+    int rc = yk_launch_alpha_finish(c, globalBBox); if (rc) return rc;
+    c->alphaFinished = true;
+    return YK_OK;
+}
+
+static int yk_fetch_alpha(yk_ctx* c, std::vector<uint8_t>& keep, int32_t b[5]) {
+    if (!c->alphaFinished) return yk_fail(c, YK_ERR_STATE, "yk_alpha_finish first");
+    YK_HIP(c, hipSetDevice(c->device));
+    keep.resize((size_t)c->mtW * c->mtH);
+    YK_HIP(c, hipMemcpyAsync(keep.data(), c->keep, keep.size(), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipMemcpyAsync(b, c->bounds, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_alpha_result(yk_ctx* c, int32_t bounds[4], int* hasChunk, int* remainingPixels, int32_t tileBBox[4]) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (c->nPlanes != 4) {                               // EncoderContext.cpp:1419-1426
+        if (bounds) { bounds[0] = 0; bounds[1] = 0; bounds[2] = c->fullW; bounds[3] = c->fullH; }
+        if (hasChunk) *hasChunk = 0;
+        if (remainingPixels) *remainingPixels = c->fullW * c->h;
+        return YK_OK;
+    }
+    std::vector<uint8_t> keep; int32_t b[5];
+    int rc = yk_fetch_alpha(c, keep, b); if (rc) return rc;
+    if (bounds) memcpy(bounds, b, 4 * sizeof(int32_t));
+    if (hasChunk) *hasChunk = b[4] ? 0 : 1;
+    if (remainingPixels) {
+        if (b[4]) *remainingPixels = c->fullW * c->h;    // :1402 (this stripe's share)
+        else { int n = 0; for (uint8_t k : keep) n += k ? 256 : 0; *remainingPixels = n; }   // :1323
+    }
+    if (tileBBox) { tileBBox[0] = b[0] >> 4; tileBBox[1] = b[1] >> 4; tileBBox[2] = (b[2] >> 4) - (b[0] >> 4); tileBBox[3] = (b[3] >> 4) - (b[1] >> 4); }
+    return YK_OK;
+}
+
+int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes) {
+    if (!c || !hostOut) return YK_ERR_BAD_ARG;
+    if (c->nPlanes != 4) { if (nBytes) *nBytes = 0; return YK_OK; }
+    std::vector<uint8_t> keep; int32_t b[5];
+    int rc = yk_fetch_alpha(c, keep, b); if (rc) return rc;
+    if (b[4] || b[2] < b[0]) { if (nBytes) *nBytes = 0; return YK_OK; }
+    const int bx0 = b[0] >> 4, by0 = b[1] >> 4, tw = (b[2] >> 4) - bx0, th = (b[3] >> 4) - by0;
+    const size_t sz = ((size_t)tw * th + 7) / 8;
+    if (cap < sz) return yk_fail(c, YK_ERR_RANGE, "alpha bitmap buffer too small");
+    memset(hostOut, 0, sz);
+    const int my0 = c->y0 >> 4;
+    for (int y = 0; y < th; y++) {                       // bit order of EncoderContext.cpp:1317-1327
+        const int my = by0 + y - my0;
+        if (my < 0 || my >= c->mtH) continue;
+        for (int x = 0; x < tw; x++) {
+            if (keep[(size_t)my * c->mtW + bx0 + x]) { const size_t bp = (size_t)y * tw + x; hostOut[bp >> 3] |= (uint8_t)(1u << (bp & 7)); }
+        }
+    }
+    if (nBytes) *nBytes = sz;
+    return YK_OK;
+}
+
+// ---- fused encode ------------------------------------------------------------------------------------
+int yk_set_dst_fill(yk_ctx* c, int32_t fill) { if (!c) return YK_ERR_BAD_ARG; c->dstFill = fill; return YK_OK; }
+
+int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
+    if (rejectFactor < 0 || rejectFactor > 64) return yk_fail(c, YK_ERR_BAD_ARG, "rejectFactor out of range");
+    if (c->nPlanes == 4 && !c->alphaFinished) return yk_fail(c, YK_ERR_STATE, "RGBA image: run yk_alpha_reject + yk_alpha_finish first (MipPrefilter precedes the tile passes)");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (wantDst) {
+        const size_t n = (size_t)c->fullW * c->h;
+        for (int p = 0; p < 3; p++) {
+            if (!c->dst[p]) YK_HIP(c, hipMalloc(&c->dst[p], n * sizeof(int32_t)));
+            if (c->dstFill == 0 || c->dstFill == -1) YK_HIP(c, hipMemsetAsync(c->dst[p], c->dstFill & 255, n * sizeof(int32_t), c->stream));
+            else {
+                std::vector<int32_t> f(n, c->dstFill);
+                YK_HIP(c, hipMemcpyAsync(c->dst[p], f.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                YK_HIP(c, hipStreamSynchronize(c->stream));
+            }
+        }
+    }
+    YK_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    int rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, wantDst); if (rc) return rc;
+    YK_HIP(c, hipEventRecord(c->ev[3], c->stream));
+    rc = yk_launch_pack(c); if (rc) return rc;
+    YK_HIP(c, hipEventRecord(c->ev[4], c->stream));
+    c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0;
+    return YK_OK;
+}
+
+size_t yk_gradient_bitmap_bytes(const yk_ctx* c, int pass) { return (c && pass >= 0 && pass < 7) ? c->bitmapBytes[pass] : 0; }
+const uint8_t* yk_gradient_bitmap_device(const yk_ctx* c, int pass) { return (c && c->encoded && pass >= 0 && pass < 7) ? c->bitmap[pass] : nullptr; }
+
+int yk_gradient_bitmap(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap) {
+    if (!c || !hostOut || pass < 0 || pass >= 7) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    if (cap < c->bitmapBytes[pass]) return yk_fail(c, YK_ERR_RANGE, "bitmap buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->bitmap[pass], c->bitmapBytes[pass], hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_gradient_counts(yk_ctx* c, int32_t counts[YK_NUM_PASSES]) {
+    if (!c || !counts) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    for (int p = 0; p < 7; p++) {
+        std::vector<uint8_t> b(c->bitmapBytes[p] + 8, 0);
+        YK_HIP(c, hipMemcpyAsync(b.data(), c->bitmap[p], c->bitmapBytes[p], hipMemcpyDeviceToHost, c->stream));
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        int n = 0;
+        for (size_t i = 0; i < c->bitmapBytes[p]; i++) n += __builtin_popcount(b[i]);
+        counts[p] = n;
+    }
+    return YK_OK;
+}
+
+int yk_coverage(yk_ctx* c, uint16_t* hostOut, size_t capElems) {
+    if (!c || !hostOut) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    const size_t n = (size_t)c->mtW * c->mtH;
+    if (capElems < n) return yk_fail(c, YK_ERR_RANGE, "coverage buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->coverage, n * 2, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_range_sizes(yk_ctx* c, int plane, size_t* nDefs, size_t* nNibbles) {
+    if (!c || plane < 0 || plane > 2) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    uint32_t t[2];
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(t, c->totals + plane * 2, sizeof t, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    if (nDefs) *nDefs = t[0];
+    if (nNibbles) *nNibbles = t[1];
+    return YK_OK;
+}
+
+int yk_range_streams(yk_ctx* c, int plane, uint16_t* hostDefs, size_t capDefs, uint8_t* hostNibbles, size_t capBytes) {
+    size_t nd = 0, nn = 0;
+    int rc = yk_range_sizes(c, plane, &nd, &nn); if (rc) return rc;
+    const size_t nb = (nn + 1) / 2;                                       // closed to a whole byte (:4525-4527)
+    if ((hostDefs && capDefs < nd) || (hostNibbles && capBytes < nb)) return yk_fail(c, YK_ERR_RANGE, "range stream buffer too small");
+    const size_t T8 = (size_t)c->tilesW * c->tilesH;
+    if (hostDefs && nd) YK_HIP(c, hipMemcpyAsync(hostDefs, c->defsOut + plane * T8, nd * 2, hipMemcpyDeviceToHost, c->stream));
+    if (hostNibbles && nb) YK_HIP(c, hipMemcpyAsync(hostNibbles, c->nibOut + plane * c->nibStride, nb, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+const uint16_t* yk_range_defs_device(const yk_ctx* c, int plane) {
+    return (c && c->encoded && plane >= 0 && plane < 3) ? c->defsOut + (size_t)plane * c->tilesW * c->tilesH : nullptr;
+}
+const uint8_t* yk_range_nibbles_device(const yk_ctx* c, int plane) {
+    return (c && c->encoded && plane >= 0 && plane < 3) ? c->nibOut + (size_t)plane * c->nibStride : nullptr;
+}
+
+int yk_range_dst(yk_ctx* c, int plane, int32_t* hostOut, size_t capElems) {
+    if (!c || !hostOut || plane < 0 || plane > 2) return YK_ERR_BAD_ARG;
+    if (!c->encoded || !c->dstValid) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles(wantDst=1) first");
+    const size_t n = (size_t)c->fullW * c->h;
+    if (capElems < n) return yk_fail(c, YK_ERR_RANGE, "dst buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->dst[plane], n * 4, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+size_t yk_export_capacity(const yk_ctx* c) {
+    if (!c || !c->tileCount) return 0;
+    size_t n = 0;
+    for (int i = 0; i < 7; i++) n += (c->bitmapBytes[i] + 15) & ~(size_t)15;
+    n += ((size_t)c->mtW * c->mtH + 15) & ~(size_t)15;
+    const size_t T8 = (size_t)c->tilesW * c->tilesH;
+    n += 3 * (((T8 * 2 + 15) & ~(size_t)15) + ((T8 * YK_SLOT + 15) & ~(size_t)15));
+    return n;
+}
+
+int yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]) {
+    if (!c || !devDst || !sizes) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    uint32_t t[6];
+    YK_HIP(c, hipMemcpyAsync(t, c->totals, sizeof t, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t T8 = (size_t)c->tilesW * c->tilesH;
+    uint8_t* d = (uint8_t*)devDst; size_t off = 0;
+    auto put = [&](const void* src, size_t n) -> int {
+        const size_t padded = (n + 15) & ~(size_t)15;
+        if (off + padded > cap) return yk_fail(c, YK_ERR_RANGE, "export buffer too small");
+        if (n) { hipError_t e = hipMemcpyAsync(d + off, src, n, hipMemcpyDeviceToDevice, c->stream); if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "export copy", e); }
+        off += padded; return YK_OK;
+    };
+    for (int i = 0; i < 7; i++) { sizes[i] = c->bitmapBytes[i]; int rc = put(c->bitmap[i], c->bitmapBytes[i]); if (rc) return rc; }
+    sizes[7] = (c->nPlanes == 4) ? (size_t)c->mtW * c->mtH : 0;
+    { int rc = put(c->keep, sizes[7]); if (rc) return rc; }
+    for (int p = 0; p < 3; p++) {
+        sizes[8 + 2 * p] = t[p * 2]; sizes[9 + 2 * p] = t[p * 2 + 1];
+        int rc = put(c->defsOut + p * T8, (size_t)t[p * 2] * 2); if (rc) return rc;
+        rc = put(c->nibOut + p * c->nibStride, ((size_t)t[p * 2 + 1] + 1) / 2); if (rc) return rc;
+    }
+    sizes[14] = off;
+    return YK_OK;
+}
+
+int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipEventSynchronize(c->ev[4]));
+    float a = 0, e = 0, p = 0;
+    if (c->nPlanes == 4 && c->alphaDone) YK_HIP(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    YK_HIP(c, hipEventElapsedTime(&e, c->ev[2], c->ev[3]));
+    YK_HIP(c, hipEventElapsedTime(&p, c->ev[3], c->ev[4]));
+    if (fusedEncodeMs) *fusedEncodeMs = e;
+    if (alphaMs) *alphaMs = a;
+    if (packMs) *packMs = p;
+    return YK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal header shared by the HIP translation units of libyaik_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/yaik_hip.h"
+
+#define YK_BLK      64      // pixels per workgroup block side (= the 64x64 swizzle block of include/YAIK_private.h:212)
+#define YK_LSTRIDE  68      // LDS row pitch in 32-bit words (65 used, 16-byte aligned rows)
+#define YK_LROWS    65
+#define YK_SLOT     32      // bytes of nibble slot per 8x8 tile-plane (64 nibbles)
+
+struct YkEncodeParams {
+    const int32_t* plane[4];
+    int strideElems;
+    int w, h;               // owned region (stripe): w = full width, h = owned rows
+    int hAvail;             // rows physically present in the bound planes (h + halo)
+    int y0;                 // first owned row in full-image coordinates
+    int fullH;
+    int rejectFactor, startMode, wantDst;
+    // alpha / bounds (device memory, written by the alpha kernels)
+    const uint8_t* keep;    // per 16x16 macro-tile keep flag of this stripe, nullptr = no alpha plane
+    const int32_t* bounds;  // [0..3] boundX0,Y0,X1,Y1 (full-image pixels), [4] discardRejects
+    // outputs
+    uint8_t* bitmap[7];
+    uint16_t* coverage;     // per macro-tile, bit = cellY*4+cellX
+    uint16_t* tileDef;      // [3][tilesW*tilesH]
+    uint8_t*  tileCount;    // [3][tilesW*tilesH]
+    uint8_t*  slots;        // [3][tilesW*tilesH][32]
+    int32_t*  dst[3];
+    int tilesW, tilesH, mtW, mtH;
+    int xBB64, yBB64, xBB32, yBB32;
+};
+
+struct yk_ctx {
+    int device = -1;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // geometry
+    int fullW = 0, fullH = 0, nPlanes = 0, y0 = 0, h = 0, halo = 0;
+    int tilesW = 0, tilesH = 0, mtW = 0, mtH = 0;
+    // input
+    const int32_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    int strideElems = 0;
+    int32_t* ownedPlanes = nullptr; size_t ownedPlanesBytes = 0;
+    // alpha
+    uint8_t* keep = nullptr;            // mtW*mtH
+    int32_t* bounds = nullptr;          // 16 ints: [0..3] global bounds, [4] discard flag, [8..11] stripe bbox accumulators
+    bool alphaDone = false, alphaFinished = false;
+    int32_t hostBounds[4] = {0, 0, 0, 0}; int hostDiscard = 1, hostHasChunk = 0;
+    // encode outputs
+    uint8_t* bitmap[7] = {}; size_t bitmapBytes[7] = {};
+    uint16_t* coverage = nullptr;
+    uint16_t* tileDef = nullptr; uint8_t* tileCount = nullptr; uint8_t* slots = nullptr;
+    int32_t* dst[3] = {nullptr, nullptr, nullptr}; int32_t dstFill = -1; bool dstValid = false;
+    // compaction
+    uint32_t* blockSums = nullptr;      // [3][nBlocks][2]
+    uint32_t* totals = nullptr;         // [3][2] device
+    uint16_t* defsOut = nullptr;        // [3][T8]
+    uint8_t*  nibOut = nullptr;         // [3][T8*32 + 8]
+    size_t nibStride = 0;
+    int nScanBlocks = 0;
+    bool encoded = false;
+    // corner streams
+    uint32_t* latticeOwner = nullptr; size_t latticeElems = 0;
+    uint8_t* cornerStream = nullptr; size_t cornerCap = 0;
+    uint32_t* cornerScratch = nullptr; size_t cornerScratchElems = 0;
+    bool cornersReady = false; int nextCornerPass = 0;
+    // decode
+    int dw = 0, dh = 0; uint8_t* dPlanes = nullptr; size_t dPlaneSize = 0;
+    uint8_t* dMapRGB = nullptr; uint32_t* dLatticeOwner = nullptr; uint8_t* dTile4 = nullptr; size_t dTile4Size = 0;
+    uint8_t* dScratch = nullptr; size_t dScratchBytes = 0;
+    bool dSplit = false;
+    // timing
+    hipEvent_t ev[6] = {};
+    float msEncode = 0, msAlpha = 0, msPack = 0;
+};
+
+int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+#define YK_HIP(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return yk_fail((c), YK_ERR_HIP, #call, _e); } while (0)
+
+// launchers implemented in the kernel TUs
+int yk_launch_alpha(yk_ctx* c);
+int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
+int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
+int yk_launch_pack(yk_ctx* c);
+int yk_launch_corners(yk_ctx* c);

@@ -1,0 +1,578 @@
+// yk_encode.hip — gfx950 kernels for the YAIK tile-encode hot path.
+//
+//   yk_alpha_kernel        a9   EncoderContext::MipPrefilter / quadRecursion   (encoder/EncoderContext.cpp:357-430, 1257-1427)
+//   yk_encode_kernel       a6   7x EncoderContext::FittingQuadSmooth           (encoder/EncoderContext.cpp:3710-4363)
+//                          a10-a13 DynamicTileEncode / GetMinMax_Y / GetTileDynamic_Y / buildTable
+//                                                                              (encoder/EncoderContext.cpp:625-1212, 4365-4602; Plane.cpp:489)
+//   yk_scan*/yk_pack       stream compaction of the per-tile results into the reference's global streams
+//                          (`streamTileDef` :4419, `streamTileIdx` :4421, nibble packing :1180-1184)
+//
+// Data layout in HBM: inputs are the reference's planar int32 `Plane`s (4 B/sample, read exactly once by the fused
+// kernel).  One workgroup (4 wave64) owns one 64x64-pixel block = one swizzle block of the tile bitmaps
+// (include/YAIK_private.h:212-276), stages its 65x65 clamped RGB samples in LDS as packed 0x00BBGGRR words, and each
+// wave walks four 16x16 macro-tiles: all seven gradient passes, then the range quantiser of the 2x2 8x8 tiles x 3 planes.
+// No MFMA: integer / byte work bounded by HBM streaming of 12-16 B/pixel.
+#include "yk_common.h"
+#include "yk_curves.h"
+
+__constant__ float c_curve[6][16] = YK_CURVE_TABLE;
+
+// ------------------------------------------------------------------------------------------------------------------
+// a9: alpha tile-reject, stage 1.  One workgroup per 64x64 block, wave w owns macro-tile row w of the block.
+// keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed form of quadRecursion with
+// maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (:416-422).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h, int y0,
+                                                       uint8_t* __restrict__ keep, int mtW, int mtH, int32_t* __restrict__ bbox /*x0,y0,x1,y1*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int mty = by * 4 + wave;
+    if (mty >= mtH) return;
+    const int gx = bx * 64 + (lane & 15) * 4;
+    int nz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int gy = mty * 16 + k * 4 + (lane >> 4);
+        if (gx < w && gy < h) {
+            const int4 a = *reinterpret_cast<const int4*>(alpha + (size_t)gy * strideElems + gx);
+            nz |= a.x | a.y | a.z | a.w;
+        }
+    }
+    const unsigned long long b = __ballot(nz != 0);
+    int x0 = 9999999, x1 = -1;
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int mtx = bx * 4 + m;
+        if (mtx >= mtW) break;
+        const bool kept = (b & (0x000F000F000F000FULL << (4 * m))) != 0;
+        if (lane == 0) keep[mty * mtW + mtx] = kept ? 1 : 0;
+        if (kept) { any = true; x0 = min(x0, mtx * 16); x1 = max(x1, mtx * 16 + 16); }
+    }
+    if (lane == 0 && any) {
+        atomicMin(&bbox[0], x0); atomicMax(&bbox[2], x1);
+        atomicMin(&bbox[1], y0 + mty * 16); atomicMax(&bbox[3], y0 + mty * 16 + 16);
+    }
+}
+
+// stage 2 when the caller does not supply an image-wide bbox: the handle's own accumulators are the whole image.
+// "bbox == whole image -> every reject discarded" (EncoderContext.cpp:1294, :1400-1403).
+__global__ void yk_alpha_finish_kernel(int32_t* bounds, int fullW, int fullH) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int x0 = bounds[8], y0 = bounds[9], x1 = bounds[10], y1 = bounds[11];
+        bounds[0] = x0; bounds[1] = y0; bounds[2] = x1; bounds[3] = y1;
+        bounds[4] = (x0 == 0 && y0 == 0 && x1 == fullW && y1 == fullH) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused gradient fit + range quantiser
+// ------------------------------------------------------------------------------------------------------------------
+struct LaneGeo {
+    int lane, cell, cx, cy, row, px0, py;   // cell = 4x4 cell of the macro-tile, lane owns pixels (px0..px0+3, py)
+};
+
+__device__ __forceinline__ int yk_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
+__device__ __forceinline__ int yk_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
+__device__ __forceinline__ int yk_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
+
+// One gradient pass over one macro-tile (a wave).  Exact integer reformulation of the test at EncoderContext.cpp:3894-3998:
+// all weights are multiples of 64 (:3735-3737), so with 1/16-unit weights S' = (TL*lx+TR*rx)*ty + (BL*lx+BR*rx)*by fits 16 bits,
+// blendCO = S'>>8 and blendC = (S'+127)>>8, and |cur-blend| <= 3 for both roundings is a range test on D = S' - 256*cur:
+//   no-rounding variant passes  <=>  -768 <= D <= 1023 ;  rounding variant passes  <=>  -895 <= D <= 896   (rejectFactor 3)
+template <int SX, int SY>
+__device__ __forceinline__ void yk_grad_pass(const uint32_t* s_pix, int lbase, const LaneGeo& g, const int (&cc)[12], unsigned long long& cov,
+                                             int gx0, int gy0, int w, int h, int rf, uint32_t* s_bm, int bx0, int by0) {
+    constexpr int TX = 1 << SX, TY = 1 << SY;
+    const int ox = g.px0 & ~(TX - 1), oy = g.py & ~(TY - 1);
+    const int ocell = (oy >> 2) * 4 + (ox >> 2);
+    const bool inside = (gx0 + ox + TX <= w) && (gy0 + oy + TY <= h);
+    const bool allow = inside && (((cov >> (ocell * 4)) & 1ULL) == 0);     // top-left pixel of the tile uncovered (:3871-3875)
+    if (__ballot(allow) == 0ULL) return;
+
+    const int wy = 16 - ((g.py - oy) << (4 - SY)), wb = 16 - wy;
+    const int dx0 = g.px0 - ox;
+    const uint32_t tl = s_pix[lbase + oy * YK_LSTRIDE + ox], tr = s_pix[lbase + oy * YK_LSTRIDE + ox + TX];
+    const uint32_t bl = s_pix[lbase + (oy + TY) * YK_LSTRIDE + ox], br = s_pix[lbase + (oy + TY) * YK_LSTRIDE + ox + TX];
+    const int loO = -256 * rf, hiO = 256 * rf + 255, loR = loO - 127, hiR = hiO - 127;
+
+    int fail = 0;
+#pragma unroll
+    for (int set = 0; set < 3; set++) {
+        int mn = 0x7fffffff, mx = -0x7fffffff;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            int a = yk_byte(tl, ch), b = yk_byte(tr, ch), c = yk_byte(bl, ch), d = yk_byte(br, ch);
+            if (set == 1) { a = yk_round6(a); b = yk_round6(b); c = yk_round6(c); d = yk_round6(d); }
+            if (set == 2) { a = yk_round6p(a); b = yk_round6p(b); c = yk_round6p(c); d = yk_round6p(d); }
+            const int L = a * wy + c * wb, R = b * wy + d * wb;
+            const int dL = L - R, R16 = R << 4;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int lx = 16 - ((dx0 + i) << (4 - SX));
+                const int D = R16 + dL * lx - cc[i * 3 + ch];
+                mn = min(mn, D); mx = max(mx, D);
+            }
+        }
+        const int fO = (mn < loO) | (mx > hiO), fR = (mn < loR) | (mx > hiR);
+        fail |= (fO | (fR << 1)) << (2 * set);
+        if (set == 0) {
+            // Round6 moves a corner by at most 3, Round6P by -2..+4 (a convex blend keeps those bounds on S'/256), so a pixel
+            // whose raw D is outside [loR-1024, hiO+768] fails all six variants.  If every allowed lane holds such a pixel the
+            // other two corner sets cannot change any decision of this wave.
+            const bool hopeless = (mn < loR - 1024) | (mx > hiO + 768);
+            if (__ballot(allow && !hopeless) == 0ULL) return;
+        }
+    }
+    // OR the 6 sticky reject flags over the lanes of each tile (lane bits: r0 r1 | cx0 cx1 | cy0 cy1)
+    fail |= __shfl_xor(fail, 1); fail |= __shfl_xor(fail, 2);
+    if (SX >= 3) fail |= __shfl_xor(fail, 4);
+    if (SX >= 4) fail |= __shfl_xor(fail, 8);
+    if (SY >= 3) fail |= __shfl_xor(fail, 16);
+    if (SY >= 4) fail |= __shfl_xor(fail, 32);
+    const bool accept = allow && (fail != 63);                                         // :3998
+    cov |= __ballot(accept && g.row == 0);                                             // paint coverage (:4029-4037)
+    if (accept && g.px0 == ox && g.py == oy) {                                         // one lane per tile sets the bitmap bit (:4026)
+        const int tbx = (bx0 + ox) >> SX, tby = (by0 + oy) >> SY;
+        int bit;
+        if (SX == 4 && SY == 4) bit = 0 + tby * 4 + tbx;
+        else if (SX == 4 && SY == 3) bit = 32 + tby * 4 + tbx;
+        else if (SX == 3 && SY == 4) bit = 64 + tby * 8 + tbx;
+        else if (SX == 3 && SY == 3) bit = 96 + tby * 8 + tbx;
+        else if (SX == 3 && SY == 2) bit = 160 + (tby >> 3) * 64 + (tby & 7) * 8 + tbx;           // two 64x32 swizzle blocks stacked
+        else if (SX == 2 && SY == 3) bit = 288 + (tbx >> 3) * 64 + tby * 8 + (tbx & 7);            // two 32x64 side by side
+        else bit = 416 + ((tby >> 3) * 2 + (tbx >> 3)) * 64 + (tby & 7) * 8 + (tbx & 7);           // four 32x32
+        atomicOr(&s_bm[bit >> 5], 1u << (bit & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pix[YK_LROWS * YK_LSTRIDE];
+    __shared__ uint32_t s_bm[24];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][4][80];
+    __shared__ __attribute__((aligned(16))) float s_chain[4][24][68];
+    __shared__ __attribute__((aligned(16))) float s_err[4][24];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int BX = blockIdx.x, BY = blockIdx.y;
+    const int w = P.w, h = P.h;
+
+    // ---- stage the clamped 65x65 block (Plane::GetPixelValue clamp, encoder/framework.h:116-121) -----------------
+    if (tid < 24) s_bm[tid] = 0;
+    {
+        const int g4 = (tid & 15) * 4, r0 = tid >> 4;
+        const int gx = BX * 64 + g4;
+        for (int r = r0; r < YK_LROWS; r += 16) {
+            const int gy = min(BY * 64 + r, P.hAvail - 1);
+            uint32_t o0, o1, o2, o3;
+            if (gx + 3 < w) {
+                const size_t off = (size_t)gy * P.strideElems + gx;
+                const int4 R = *reinterpret_cast<const int4*>(P.plane[0] + off);
+                const int4 G = *reinterpret_cast<const int4*>(P.plane[1] + off);
+                const int4 B = *reinterpret_cast<const int4*>(P.plane[2] + off);
+                o0 = (uint32_t)R.x | ((uint32_t)G.x << 8) | ((uint32_t)B.x << 16);
+                o1 = (uint32_t)R.y | ((uint32_t)G.y << 8) | ((uint32_t)B.y << 16);
+                o2 = (uint32_t)R.z | ((uint32_t)G.z << 8) | ((uint32_t)B.z << 16);
+                o3 = (uint32_t)R.w | ((uint32_t)G.w << 8) | ((uint32_t)B.w << 16);
+            } else {
+                const size_t off = (size_t)gy * P.strideElems + (w - 1);
+                o0 = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
+                o1 = o2 = o3 = o0;
+            }
+            *reinterpret_cast<uint4*>(&s_pix[r * YK_LSTRIDE + g4]) = make_uint4(o0, o1, o2, o3);
+        }
+        if (tid < YK_LROWS) {      // right halo column
+            const int gy = min(BY * 64 + tid, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
+            const size_t off = (size_t)gy * P.strideElems + gxh;
+            s_pix[tid * YK_LSTRIDE + 64] = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
+        }
+    }
+    __syncthreads();
+
+    LaneGeo g;
+    g.lane = lane; g.cell = lane >> 2; g.cx = g.cell & 3; g.cy = g.cell >> 2; g.row = lane & 3;
+    g.px0 = g.cx * 4; g.py = g.cy * 4 + g.row;
+    const int jt = ((g.cy & 1) * 2 + (g.cx & 1)) * 4 + g.row;         // lane index inside its 8x8 tile (0..15)
+    const int t8 = (g.cy >> 1) * 2 + (g.cx >> 1);                     // which of the 2x2 8x8 tiles
+    float crv[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) crv[m] = c_curve[m][m < 3 ? jt : (jt & 7)];
+
+    // constraint box of DynamicTileEncode (:4386-4391) in full-image pixels
+    int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;
+    if (P.bounds) {
+        const int b0 = P.bounds[0], b1 = P.bounds[1], b2 = P.bounds[2], b3 = P.bounds[3];
+        discard = P.bounds[4];
+        cxB = (b0 >> 3) << 3; cyB = (b1 >> 3) << 3;
+        cw = (((b2 + 7) >> 3) << 3) - cxB; chh = (((b3 + 7) >> 3) << 3) - cyB;
+    }
+
+    for (int q = 0; q < 4; q++) {
+        const int mtxl = q, mtyl = wave;                  // macro-tile inside the block
+        const int bx0 = mtxl * 16, by0 = mtyl * 16;
+        const int gx0 = BX * 64 + bx0, gy0 = BY * 64 + by0;      // stripe-local pixel origin of the macro-tile
+        if (gx0 >= w || gy0 >= h) continue;                // wave-uniform
+        const int lbase = by0 * YK_LSTRIDE + bx0;
+        const uint4 pw = *reinterpret_cast<const uint4*>(&s_pix[lbase + g.py * YK_LSTRIDE + g.px0]);
+        const uint32_t pix[4] = { pw.x, pw.y, pw.z, pw.w };
+        int cc[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) cc[i * 3 + ch] = yk_byte(pix[i], ch) << 8;
+
+        // ---- a6: the seven passes in the shipped order (EncoderContext.cpp:9057-9093) -------------------------
+        unsigned long long cov = 0ULL;                    // bit 4*cell = cell covered (mapSmoothTile != 0)
+        yk_grad_pass<4, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+        if (cov != 0x1111111111111111ULL) {
+            yk_grad_pass<4, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+            yk_grad_pass<3, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+            yk_grad_pass<3, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+            yk_grad_pass<3, 2>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+            yk_grad_pass<2, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+            yk_grad_pass<2, 2>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+        }
+        const int mtIdx = (gy0 >> 4) * P.mtW + (gx0 >> 4);
+        if (lane == 0) {
+            unsigned long long c = cov; uint32_t bits = 0;
+            for (int k = 0; k < 16; k++) bits |= (uint32_t)((c >> (4 * k)) & 1ULL) << k;
+            P.coverage[mtIdx] = (uint16_t)bits;
+        }
+
+        // ---- a10-a13: range quantiser of the 2x2 8x8 tiles x 3 planes ------------------------------------------
+        const int tgx = gx0 + (g.cx >> 1) * 8, tgyl = gy0 + (g.cy >> 1) * 8;        // tile origin, stripe-local
+        const int tgy = tgyl + P.y0;                                                // full-image row
+        const bool tileIn = (tgx + 8 <= w) && (tgyl + 8 <= h);
+        // LeftRightOrder over the constraint box, including its zero-size rule (encoder/framework.h:239-255):
+        // result.w = (x + 8 > constraint.w) ? 0 : 8, likewise h  -> such tiles carry no pixel.
+        const bool part = tileIn && tgx >= cxB && tgx < cxB + cw && tgy >= cyB && tgy < cyB + chh && (tgx + 8 <= cw) && (tgy + 8 <= chh);
+        const bool keepMT = (P.keep == nullptr) || discard || (P.keep[mtIdx] != 0);
+        // validity of the four cells of this lane's tile: valid = mipmapMask && !smoothMap (Plane.cpp:527)
+        const int c00 = ((g.cy & ~1) * 4 + (g.cx & ~1));
+        const bool v00 = !((cov >> (4 * c00)) & 1ULL), v10 = !((cov >> (4 * (c00 + 1))) & 1ULL);
+        const bool v01 = !((cov >> (4 * (c00 + 4))) & 1ULL), v11 = !((cov >> (4 * (c00 + 5))) & 1ULL);
+        const bool tileLive = part && keepMT;
+        const bool valid = tileLive && !((cov >> (4 * g.cell)) & 1ULL);
+        const int nTop = (int)v00 + (int)v10, nBot = (int)v01 + (int)v11;
+        const int valueCount = tileLive ? 16 * (nTop + nBot) : 0;
+        const int tileIdx = (tgyl >> 3) * P.tilesW + (tgx >> 3);
+        const size_t T8 = (size_t)P.tilesW * P.tilesH;
+        const unsigned long long anyValid = __ballot(valid);
+
+        if (anyValid == 0ULL) {
+            if (jt == 0 && tileIn) {
+#pragma unroll
+                for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
+            }
+            continue;
+        }
+        // nibble position of this lane's 4 pixels among the valid pixels of the tile, row-major (:1174-1190)
+        const int yIn = (g.cy & 1) * 4 + g.row, xc = g.cx & 1;
+        const int pos = (yIn < 4) ? (yIn * 4 * nTop + (xc ? 4 * (int)v00 : 0))
+                                  : (16 * nTop + (yIn - 4) * 4 * nBot + (xc ? 4 * (int)v01 : 0));
+        const int p0 = yIn * 8 + xc * 4;                 // row-major pixel index inside the tile
+
+        for (int p = 0; p < 3; p++) {
+            int v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = yk_byte(pix[i], p);
+            // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
+            int mn = valid ? min(min(v[0], v[1]), min(v[2], v[3])) : 99999999;
+            int mx = valid ? max(max(v[0], v[1]), max(v[2], v[3])) : -99999999;
+            mn = min(mn, __shfl_xor(mn, 1)); mx = max(mx, __shfl_xor(mx, 1));
+            mn = min(mn, __shfl_xor(mn, 2)); mx = max(mx, __shfl_xor(mx, 2));
+            mn = min(mn, __shfl_xor(mn, 4)); mx = max(mx, __shfl_xor(mx, 4));
+            mn = min(mn, __shfl_xor(mn, 16)); mx = max(mx, __shfl_xor(mx, 16));
+            if (mn == 99999999) { mn = 0; mx = 0; }
+            // DynamicTile::buildTable (:625-699)
+            const int min_ = min(mn, 224);
+            int diff = mx - min_; if (diff < 16) diff = 16;
+            const int base = (min_ * 63 + 112) / 224;
+            const int BN = (base * 224) / 63;
+            const int d8 = max(diff, 32);
+            const int scale = 223 - BN;
+            const int dist = ((d8 - 32) * 127 + (scale - 1)) / scale;
+            const int rangeDecode = (dist * scale) / 127 + 32;
+            const float Rf = (float)rangeDecode, BNf = (float)BN;
+            // lane jt of the tile builds entry jt of every curve; stored pre-shifted (<<4) so that one v_sad_u32 yields
+            // (|LUT-v| << 4) + n  and a plain minimum returns the FIRST nearest entry (:873-881)
+            uint16_t* lut = &s_lut[wave][t8][0];
+#pragma unroll
+            for (int m = 0; m < 3; m++) lut[m * 16 + jt] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(crv[m], Rf))) << 4);
+            if (jt < 8) {
+#pragma unroll
+                for (int m = 3; m < 6; m++) lut[48 + (m - 3) * 8 + jt] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(crv[m], Rf))) << 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            uint32_t key[6][4];
+            uint32_t vs[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) vs[i] = (uint32_t)v[i] << 4;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                const int cnt = m < 3 ? 16 : 8;
+                const uint32_t* lw = reinterpret_cast<const uint32_t*>(lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8));
+#pragma unroll
+                for (int i = 0; i < 4; i++) key[m][i] = 0xFFFFFFFFu;
+                if (m >= P.startMode) {
+#pragma unroll
+                    for (int k = 0; k < cnt / 2; k++) {
+                        const uint32_t wv = lw[k];
+                        const uint32_t e0 = wv & 0xFFFFu, e1 = wv >> 16;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            key[m][i] = min(key[m][i], __usad(e0, vs[i], 2 * k));
+                            key[m][i] = min(key[m][i], __usad(e1, vs[i], 2 * k + 1));
+                        }
+                    }
+                }
+            }
+            // per-pixel relative error terms (:884-886), IEEE division, handed to the chain lanes through LDS
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                float qv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float md = (float)(int)(key[m][i] >> 4);
+                    qv[i] = (valid && v[i] != 0 && m >= P.startMode) ? __fdiv_rn(md, (float)v[i]) : 0.0f;
+                }
+                *reinterpret_cast<float4*>(&s_chain[wave][t8 * 6 + m][p0]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // sequential float sum in row-major pixel order, one lane per (tile, mode): errorDist += minDiff / v (:885)
+            if (lane < 24) {
+                float s = 0.0f;
+                const float4* cp = reinterpret_cast<const float4*>(&s_chain[wave][lane][0]);
+#pragma unroll 4
+                for (int k = 0; k < 16; k++) {
+                    const float4 a = cp[k];
+                    s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, a.x), a.y), a.z), a.w);
+                }
+                s_err[wave][lane] = s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // best mode: last mode whose error is <= the best so far (:897-905)
+            int bestMode = -1; float bestErr = 99999999.0f;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                const float e = s_err[wave][t8 * 6 + m];
+                if (m >= P.startMode && e <= bestErr) { bestErr = e; bestMode = m; }
+            }
+            uint32_t code4 = 0;
+            int code[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t k = key[0][i];
+#pragma unroll
+                for (int m = 1; m < 6; m++) k = (bestMode == m) ? key[m][i] : k;
+                code[i] = (int)(k & 15u);
+                code4 |= (uint32_t)code[i] << (4 * i);
+            }
+            if (valid) {
+                *reinterpret_cast<uint16_t*>(P.slots + ((size_t)p * T8 + tileIdx) * YK_SLOT + (pos >> 1)) = (uint16_t)code4;
+                if (P.wantDst) {
+                    const uint16_t* lb = lut + (bestMode < 3 ? bestMode * 16 : 48 + (bestMode - 3) * 8);
+                    int32_t* drow = P.dst[p] + (size_t)(gy0 + g.py) * w + gx0 + g.px0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) drow[i] = (int32_t)(lb[code[i]] >> 4);
+                }
+            }
+            if (jt == 0 && tileIn) {
+                P.tileCount[p * T8 + tileIdx] = (uint8_t)valueCount;
+                // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
+                P.tileDef[p * T8 + tileIdx] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (((uint32_t)dist & 255u) << 7) | ((uint32_t)base & 255u));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- block bitmaps -> the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805) -----------
+    __syncthreads();
+    if (tid == 0) {
+        const int i64 = BY * P.xBB64 + BX;
+        reinterpret_cast<uint16_t*>(P.bitmap[0])[i64] = (uint16_t)s_bm[0];
+        reinterpret_cast<uint32_t*>(P.bitmap[1])[i64] = s_bm[1];
+        reinterpret_cast<uint32_t*>(P.bitmap[2])[i64] = s_bm[2];
+        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2] = s_bm[3];
+        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2 + 1] = s_bm[4];
+        for (int s = 0; s < 2; s++) {
+            if (BY * 2 + s < P.yBB32) {                                   // 8x4: 64x32 swizzle blocks
+                const int i = (BY * 2 + s) * P.xBB64 + BX;
+                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2] = s_bm[5 + s * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2 + 1] = s_bm[6 + s * 2];
+            }
+            if (BX * 2 + s < P.xBB32) {                                   // 4x8: 32x64 swizzle blocks
+                const int i = BY * P.xBB32 + BX * 2 + s;
+                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2] = s_bm[9 + s * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2 + 1] = s_bm[10 + s * 2];
+            }
+        }
+        for (int sy = 0; sy < 2; sy++) for (int sx = 0; sx < 2; sx++) {   // 4x4: 32x32 swizzle blocks
+            if (BY * 2 + sy < P.yBB32 && BX * 2 + sx < P.xBB32) {
+                const int i = (BY * 2 + sy) * P.xBB32 + BX * 2 + sx;
+                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2] = s_bm[13 + (sy * 2 + sx) * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2 + 1] = s_bm[14 + (sy * 2 + sx) * 2];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stream compaction: per-tile (count, def, 32-byte nibble slot) -> the reference's global streams, LeftRightOrder =
+// row-major over the tile grid (tiles outside the constraint box carry count 0).
+// ------------------------------------------------------------------------------------------------------------------
+#define YK_SCAN_TILE 1024
+
+__device__ __forceinline__ uint32_t yk_block_exscan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
+    // exclusive scan over the 1024 threads of a block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+    if (lane == 63) s_tmp[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t t = lane < 16 ? s_tmp[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { uint32_t y = __shfl_up(t, d); if (lane >= d) t += y; }
+        if (lane < 16) s_tmp[16 + lane] = t;
+    }
+    __syncthreads();
+    const uint32_t waveBase = wave ? s_tmp[16 + wave - 1] : 0;
+    *total = s_tmp[16 + 15];
+    __syncthreads();
+    return waveBase + x - v;
+}
+
+__global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restrict__ tileCount, size_t T8, uint32_t* __restrict__ blockSums, int nBlocks) {
+    __shared__ uint32_t s_tmp[32];
+    const int p = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
+    const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+    uint32_t tot2, totN;
+    yk_block_exscan(c ? 1u : 0u, s_tmp, &tot2);
+    yk_block_exscan(c, s_tmp, &totN);
+    if (threadIdx.x == 0) { blockSums[((size_t)p * nBlocks + blockIdx.x) * 2] = totN; blockSums[((size_t)p * nBlocks + blockIdx.x) * 2 + 1] = tot2; }
+}
+
+__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockSums, int nBlocks, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tmp[32];
+    const int p = blockIdx.x;
+    uint32_t* bs = blockSums + (size_t)p * nBlocks * 2;
+    uint32_t baseN = 0, baseD = 0;
+    for (int start = 0; start < nBlocks; start += 1024) {
+        const int i = start + threadIdx.x;
+        const uint32_t n = i < nBlocks ? bs[i * 2] : 0, d = i < nBlocks ? bs[i * 2 + 1] : 0;
+        uint32_t totN, totD;
+        const uint32_t en = yk_block_exscan(n, s_tmp, &totN);
+        const uint32_t ed = yk_block_exscan(d, s_tmp, &totD);
+        if (i < nBlocks) { bs[i * 2] = baseN + en; bs[i * 2 + 1] = baseD + ed; }
+        baseN += totN; baseD += totD;
+    }
+    if (threadIdx.x == 0) { totals[p * 2] = baseD; totals[p * 2 + 1] = baseN; }
+}
+
+__global__ __launch_bounds__(256) void yk_zero_kernel(uint32_t* __restrict__ nib, size_t strideWords, const uint32_t* __restrict__ totals) {
+    const int p = blockIdx.y;
+    const size_t words = ((size_t)totals[p * 2 + 1] + 7) / 8 + 1;
+    uint32_t* o = nib + (size_t)p * strideWords;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) o[i] = 0;
+}
+
+__global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
+                                                       const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
+                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords) {
+    __shared__ uint32_t s_tmp[32];
+    const int p = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
+    const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+    uint32_t tot;
+    const uint32_t en = yk_block_exscan(c, s_tmp, &tot);
+    const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &tot);
+    if (!c) return;
+    const uint32_t baseN = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2], baseD = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2 + 1];
+    defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
+    // copy c nibbles from the tile slot to nibble offset o of the plane's stream (low nibble first)
+    const uint32_t o = baseN + en;
+    const uint32_t* sl = reinterpret_cast<const uint32_t*>(slots + ((size_t)p * T8 + i) * YK_SLOT);
+    uint32_t* out = nibOut + (size_t)p * nibStrideWords;
+    const uint32_t sh = (o & 7u) * 4u;
+    const uint32_t firstW = o >> 3, lastW = (o + c - 1) >> 3;
+    uint32_t carry = 0;
+    const uint32_t nW = (c + 7) >> 3;
+    for (uint32_t k = 0; k <= nW; k++) {
+        uint32_t wv = 0;
+        if (k < nW) {
+            wv = sl[k];
+            const uint32_t rem = c - k * 8;                       // nibbles of this word that are real
+            if (rem < 8) wv &= (1u << (rem * 4)) - 1u;
+        }
+        const uint32_t outw = sh ? ((wv << sh) | carry) : wv;
+        carry = sh ? (wv >> (32 - sh)) : 0;
+        const uint32_t wi = firstW + k;
+        if (wi > lastW) break;
+        if (wi == firstW || wi == lastW) atomicOr(&out[wi], outw); else out[wi] = outw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+int yk_launch_alpha(yk_ctx* c) {
+    static const int32_t init[16] = { 0, 0, 0, 0, 1, 0, 0, 0, 9999999, 9999999, -1, -1, 0, 0, 0, 0 };
+    YK_HIP(c, hipMemcpyAsync(c->bounds, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    dim3 grid((c->fullW + 63) / 64, (c->h + 63) / 64);
+    hipLaunchKernelGGL(yk_alpha_kernel, grid, dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h, c->y0,
+                       c->keep, c->mtW, c->mtH, c->bounds + 8);
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
+
+int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox) {
+    if (globalBBox) {
+        int32_t b[5] = { globalBBox[0], globalBBox[1], globalBBox[2], globalBBox[3], 0 };
+        b[4] = (b[0] == 0 && b[1] == 0 && b[2] == c->fullW && b[3] == c->fullH) ? 1 : 0;
+        YK_HIP(c, hipMemcpyAsync(c->bounds, b, sizeof b, hipMemcpyHostToDevice, c->stream));
+    } else {
+        hipLaunchKernelGGL(yk_alpha_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->bounds, c->fullW, c->fullH);
+        YK_HIP(c, hipGetLastError());
+    }
+    return YK_OK;
+}
+
+int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) {
+    YkEncodeParams P;
+    for (int i = 0; i < 4; i++) P.plane[i] = c->plane[i];
+    P.strideElems = c->strideElems; P.w = c->fullW; P.h = c->h; P.hAvail = c->h + c->halo; P.y0 = c->y0; P.fullH = c->fullH;
+    P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst;
+    P.keep = (c->nPlanes == 4) ? c->keep : nullptr;
+    P.bounds = (c->nPlanes == 4) ? c->bounds : nullptr;
+    for (int i = 0; i < 7; i++) P.bitmap[i] = c->bitmap[i];
+    P.coverage = c->coverage; P.tileDef = c->tileDef; P.tileCount = c->tileCount; P.slots = c->slots;
+    for (int i = 0; i < 3; i++) P.dst[i] = c->dst[i];
+    P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
+    P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
+    dim3 grid(P.xBB64, P.yBB64);
+    hipLaunchKernelGGL(yk_encode_kernel, grid, dim3(256), 0, c->stream, P);
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
+
+int yk_launch_pack(yk_ctx* c) {
+    const size_t T8 = (size_t)c->tilesW * c->tilesH;
+    const int nb = c->nScanBlocks;
+    hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockSums, nb);
+    hipLaunchKernelGGL(yk_scan2_kernel, dim3(3), dim3(1024), 0, c->stream, c->blockSums, nb, c->totals);
+    hipLaunchKernelGGL(yk_zero_kernel, dim3(512, 3), dim3(256), 0, c->stream, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4, c->totals);
+    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, c->tileDef, c->slots, T8, c->blockSums, nb,
+                       c->defsOut, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}

@@ -1,0 +1,104 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The hot path shards with no data-path collective: units (16x16 macro-tiles, 8x8 tile-planes) are independent given
+their pixels.  Two layouts are supported:
+  * frame sharding  (batches: every rank encodes whole frames)            -> nothing but the final gather;
+  * row stripes     (one large image: rank r owns rows [r*H/N, (r+1)*H/N), multiples of 64, + 1 halo row)
+                    -> one tiny host min/max-combine of the alpha bounding boxes, then the final gather.
+The only collective on the data path is ONE gather that concatenates the per-rank tile maps on the root.
+Works with CPU tensors on gloo as well (used by the world_size-2 CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def stripe_rows(full_h: int, world: int, rank: int) -> tuple[int, int, int]:
+    """(y0, h, halo_rows) of rank's stripe: heights are multiples of 64, the last rank takes the remainder."""
+    blocks = (full_h + 63) // 64
+    per = (blocks + world - 1) // world
+    y0 = min(rank * per * 64, full_h)
+    y1 = min((rank + 1) * per * 64, full_h)
+    halo = 1 if y1 < full_h and y1 > y0 else 0
+    return y0, y1 - y0, halo
+
+
+def combine_bboxes(boxes: np.ndarray) -> np.ndarray:
+    """min/max-combine per-stripe kept-tile bounding boxes {x0,y0,x1,y1} (empty = {9999999,9999999,-1,-1})."""
+    boxes = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
+    return np.array([boxes[:, 0].min(), boxes[:, 1].min(), boxes[:, 2].max(), boxes[:, 3].max()], dtype=np.int32)
+
+
+def allreduce_bbox(bbox: np.ndarray, dist, device) -> np.ndarray:
+    """Image-wide bbox from per-rank stripe boxes: two tiny all-reduces (MIN on x0,y0 / MAX on x1,y1)."""
+    import torch
+    lo = torch.tensor([int(bbox[0]), int(bbox[1])], dtype=torch.int32, device=device)
+    hi = torch.tensor([int(bbox[2]), int(bbox[3])], dtype=torch.int32, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    lo = lo.cpu().numpy(); hi = hi.cpu().numpy()
+    return np.array([lo[0], lo[1], hi[0], hi[1]], dtype=np.int32)
+
+
+def gather_tile_maps(blob, nbytes: int, sizes: np.ndarray, dist, dst: int = 0):
+    """ONE gather of the per-rank tile-map blobs (uint8 tensors, device or CPU) onto rank `dst`.
+
+    Ranks first agree on the padded length (all_gather of 16 int64: payload bytes + the 15 section sizes), then
+    gather equal-size slices.  Returns on dst: list of (sizes[15], uint8 tensor view of that rank's payload); else None.
+    """
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    meta = torch.zeros(16, dtype=torch.int64, device=blob.device)
+    meta[0] = int(nbytes)
+    meta[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=blob.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = torch.stack(metas).cpu().numpy()
+    pad = int(metas[:, 0].max())
+    pad = (pad + 255) & ~255
+    send = blob[:pad] if blob.numel() >= pad else torch.cat([blob, blob.new_zeros(pad - blob.numel())])
+    if rank == dst:
+        recv = [torch.empty(pad, dtype=torch.uint8, device=blob.device) for _ in range(world)]
+        dist.gather(send, recv, dst=dst)
+        return [(metas[r, 1:16].copy(), recv[r][: int(metas[r, 0])]) for r in range(world)]
+    dist.gather(send, None, dst=dst)
+    return None
+
+
+def split_blob(sizes: np.ndarray, payload) -> dict:
+    """Inverse of yk_export_tile_maps' layout: dict of numpy arrays from one rank's payload (CPU uint8 array/tensor)."""
+    buf = payload.cpu().numpy() if hasattr(payload, "cpu") else np.asarray(payload, dtype=np.uint8)
+    out, off = {}, 0
+
+    def take(n):
+        nonlocal off
+        v = buf[off: off + n]
+        off += (n + 15) & ~15
+        return v
+    out["bitmaps"] = [take(int(sizes[i])).copy() for i in range(7)]
+    out["keep"] = take(int(sizes[7])).copy()
+    out["defs"], out["nibbles"], out["n_nibbles"] = [], [], []
+    for p in range(3):
+        nd, nn = int(sizes[8 + 2 * p]), int(sizes[9 + 2 * p])
+        out["defs"].append(take(nd * 2).copy().view(np.uint16))
+        out["nibbles"].append(take((nn + 1) // 2).copy())
+        out["n_nibbles"].append(nn)
+    return out
+
+
+def concat_nibble_streams(streams: list[np.ndarray], counts: list[int]) -> tuple[np.ndarray, int]:
+    """Concatenate per-stripe nibble streams (low nibble first) into the image-wide stream of DynamicTileEncode."""
+    total = int(sum(counts))
+    out = np.zeros((total + 1) // 2, dtype=np.uint8)
+    pos = 0
+    for s, n in zip(streams, counts):
+        if n == 0:
+            continue
+        nib = np.empty(2 * len(s), dtype=np.uint8)
+        nib[0::2] = s & 15
+        nib[1::2] = s >> 4
+        nib = nib[:n]
+        idx = pos + np.arange(n)
+        np.bitwise_or.at(out, idx >> 1, (nib << ((idx & 1) * 4)).astype(np.uint8))
+        pos += n
+    return out, total

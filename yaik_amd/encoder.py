@@ -1,0 +1,171 @@
+"""Python plumbing over the C-ABI (include/yaik_hip.h) for tests and bench.py.
+
+The method names follow the reference's operator surface for this path
+(``EncoderContext::MipPrefilter / FittingQuadSmooth / DynamicTileEncode``, encoder/EncoderContext.h:326-370):
+one fused launch computes what the seven FittingQuadSmooth calls and the three DynamicTileEncode calls
+compute; the per-call views below hand out the cached results.  The C++ mirror of the same surface lives in
+yaik_amd/host/ (the reference is compiled C++, so that is the drop-in; this module only moves bytes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import YaikError, lib
+
+PASSES = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]   # EncoderContext.cpp:9057-9093
+
+
+def _chk(h, rc: int):
+    if rc != 0:
+        msg = lib().yk_last_error(h)
+        raise YaikError(f"yaik_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+class HipTileEncoder:
+    """One handle = one GPU = one image or one row stripe of an image."""
+
+    def __init__(self, device: int = 0):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.yk_create(device, C.byref(h))
+        if rc != 0:
+            raise YaikError(f"yk_create failed ({rc}): no usable HIP device -- the product path has no CPU fallback")
+        self._h = h
+        self._keepalive = None
+        self.w = self.h = self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().yk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- EncoderContext::SetImageToEncode ----------------------------------------------------------
+    def set_image(self, planes, full_h: int | None = None, y0: int = 0, halo_rows: int = 0):
+        """planes: numpy int32 [n, rows, w] (uploaded) or torch int32 cuda tensor [n, rows, w] (bound in place).
+        rows = owned rows + halo_rows."""
+        L = lib()
+        is_torch = hasattr(planes, "data_ptr")
+        n, rows, w = planes.shape
+        h = rows - halo_rows
+        self.n, self.h, self.w = n, h, w
+        self.full_h = full_h if full_h is not None else h
+        self.y0 = y0
+        _chk(self._h, L.yk_set_image(self._h, w, self.full_h, n, y0, h, halo_rows))
+        if is_torch:
+            import torch
+            assert planes.dtype == torch.int32 and planes.is_cuda and planes.is_contiguous()
+            base = planes.data_ptr()
+            ptrs = (C.c_void_p * 4)(*[base + i * rows * w * 4 if i < n else None for i in range(4)])
+            stream = torch.cuda.current_stream(planes.device).cuda_stream
+            _chk(self._h, L.yk_set_stream(self._h, C.c_void_p(stream)))
+            _chk(self._h, L.yk_bind_device_planes(self._h, ptrs, w))
+        else:
+            planes = np.ascontiguousarray(planes, dtype=np.int32)
+            ptrs = (C.c_void_p * 4)(*[planes[i].ctypes.data if i < n else None for i in range(4)])
+            _chk(self._h, L.yk_upload_planes(self._h, ptrs, w))
+            _chk(self._h, L.yk_synchronize(self._h))
+        self._keepalive = planes
+
+    # ---- EncoderContext::MipPrefilter ---------------------------------------------------------------
+    def alpha_reject(self):
+        _chk(self._h, lib().yk_alpha_reject(self._h))
+
+    def stripe_bbox(self) -> np.ndarray:
+        b = np.zeros(4, dtype=np.int32)
+        _chk(self._h, lib().yk_get_stripe_bbox(self._h, b.ctypes.data))
+        return b
+
+    def alpha_finish(self, global_bbox: np.ndarray | None = None):
+        if global_bbox is None:
+            _chk(self._h, lib().yk_alpha_finish(self._h, None))
+        else:
+            g = np.ascontiguousarray(global_bbox, dtype=np.int32)
+            _chk(self._h, lib().yk_alpha_finish(self._h, g.ctypes.data))
+
+    def mip_prefilter(self) -> dict:
+        """Whole-image MipPrefilter: reject + finish + results (mirrors oracle.pyoracle.OracleEncoder.mip_prefilter)."""
+        if self.n == 4:
+            self.alpha_reject()
+            self.alpha_finish(None)
+        return self.alpha_result()
+
+    def alpha_result(self) -> dict:
+        L = lib()
+        b = np.zeros(4, dtype=np.int32); tb = np.zeros(4, dtype=np.int32)
+        has, rem = C.c_int(), C.c_int()
+        _chk(self._h, L.yk_alpha_result(self._h, b.ctypes.data, C.byref(has), C.byref(rem), tb.ctypes.data))
+        out = np.zeros(max(1, (self.w // 16) * (self.full_h // 16) // 8 + 8), dtype=np.uint8)
+        nb = C.c_size_t()
+        _chk(self._h, L.yk_alpha_bitmap(self._h, out.ctypes.data, out.size, C.byref(nb)))
+        return {"has_chunk": bool(has.value), "bounds": b, "remaining": rem.value, "tile_bbox": tb, "bitmap": out[:nb.value].copy()}
+
+    # ---- 7x FittingQuadSmooth + 3x DynamicTileEncode, one launch ---------------------------------------
+    def encode(self, reject_factor: int = 3, mode3bit_only: bool = False, want_dst: bool = False, dst_fill: int = -1):
+        L = lib()
+        _chk(self._h, L.yk_set_dst_fill(self._h, dst_fill))
+        _chk(self._h, L.yk_encode_tiles(self._h, reject_factor, int(mode3bit_only), int(want_dst)))
+
+    def synchronize(self):
+        _chk(self._h, lib().yk_synchronize(self._h))
+
+    def gradient_bitmap(self, p: int) -> np.ndarray:
+        L = lib()
+        n = L.yk_gradient_bitmap_bytes(self._h, p)
+        out = np.zeros(n, dtype=np.uint8)
+        _chk(self._h, L.yk_gradient_bitmap(self._h, p, out.ctypes.data, n))
+        return out
+
+    def gradient_counts(self) -> np.ndarray:
+        c = np.zeros(7, dtype=np.int32)
+        _chk(self._h, lib().yk_gradient_counts(self._h, c.ctypes.data))
+        return c
+
+    def coverage(self) -> np.ndarray:
+        """[h/4, w/4] bool: 4x4 cell covered by an accepted gradient tile (smoothMap != 0)."""
+        mtw, mth = (self.w + 15) // 16, (self.h + 15) // 16
+        raw = np.zeros(mtw * mth, dtype=np.uint16)
+        _chk(self._h, lib().yk_coverage(self._h, raw.ctypes.data, raw.size))
+        bits = (raw.reshape(mth, mtw, 1) >> np.arange(16, dtype=np.uint16)) & 1
+        cells = bits.reshape(mth, mtw, 4, 4).transpose(0, 2, 1, 3).reshape(mth * 4, mtw * 4)
+        return cells[: self.h // 4, : self.w // 4].astype(bool)
+
+    def gradient_corners(self, p: int) -> np.ndarray:
+        cap = (self.w // 4 + 1) * (self.h // 4 + 2) * 3 + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        nb = C.c_size_t()
+        _chk(self._h, lib().yk_gradient_corners(self._h, p, out.ctypes.data, cap, C.byref(nb)))
+        return out[:nb.value].copy()
+
+    def range_streams(self, plane: int):
+        L = lib()
+        nd, nn = C.c_size_t(), C.c_size_t()
+        _chk(self._h, L.yk_range_sizes(self._h, plane, C.byref(nd), C.byref(nn)))
+        defs = np.zeros(nd.value, dtype=np.uint16)
+        nib = np.zeros((nn.value + 1) // 2, dtype=np.uint8)
+        _chk(self._h, L.yk_range_streams(self._h, plane, defs.ctypes.data if defs.size else None, defs.size,
+                                          nib.ctypes.data if nib.size else None, nib.size))
+        return defs, nib, nn.value
+
+    def range_dst(self, plane: int) -> np.ndarray:
+        out = np.zeros((self.h, self.w), dtype=np.int32)
+        _chk(self._h, lib().yk_range_dst(self._h, plane, out.ctypes.data, out.size))
+        return out
+
+    def export_capacity(self) -> int:
+        return int(lib().yk_export_capacity(self._h))
+
+    def export_tile_maps(self, dev_buffer) -> np.ndarray:
+        """dev_buffer: torch uint8 cuda tensor of >= export_capacity() bytes. Returns the 15 section sizes."""
+        sizes = np.zeros(15, dtype=np.uint64)
+        _chk(self._h, lib().yk_export_tile_maps(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(), sizes.ctypes.data))
+        return sizes
+
+    def kernel_ms(self) -> dict:
+        e, a, p = C.c_float(), C.c_float(), C.c_float()
+        _chk(self._h, lib().yk_last_kernel_ms(self._h, C.byref(e), C.byref(a), C.byref(p)))
+        return {"encode": e.value, "alpha": a.value, "pack": p.value}

@@ -64,3 +64,42 @@ def synth_planes(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12
         holes = (((x >> 7) + (y >> 7)) % 5) == 0
         planes.append(np.where(frame | holes, 0, 255))
     return np.ascontiguousarray(np.stack(planes).astype(np.int32))
+
+
+def synth_planes_torch(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12345, device="cuda"):
+    """Same image as synth_planes, generated on `device` with torch (int32 tensor [n, h, w]).
+    The LCG is evaluated in closed form per pixel (affine-map power by squaring, mod 2^32)."""
+    import torch
+    if h is None:
+        h = w
+    W = w
+    n = w * h
+    M = 0xFFFFFFFF
+    k = torch.arange(1, n + 1, dtype=torch.int64, device=device)          # pixel i uses LCG^(i+1)(seed)
+    A = torch.ones(n, dtype=torch.int64, device=device)
+    Cc = torch.zeros(n, dtype=torch.int64, device=device)
+    pa, pc = _A, _C
+    for bit in range(max(1, int(n).bit_length())):
+        sel = ((k >> bit) & 1).bool()
+        A = torch.where(sel, (A * pa) & M, A)
+        Cc = torch.where(sel, (Cc * pa + pc) & M, Cc)
+        pc = (pa * pc + pc) & M
+        pa = (pa * pa) & M
+    s = ((A * (seed & M) + Cc) & M).reshape(h, w)
+    del A, Cc, k
+    y = torch.arange(h, dtype=torch.int64, device=device).reshape(h, 1).expand(h, w)
+    x = torch.arange(w, dtype=torch.int64, device=device).reshape(1, w).expand(h, w)
+    kk = ((x >> 6) + (y >> 6)) & 3
+    base = [(255 * x) // W, torch.clamp((255 * y) // W, max=255), torch.clamp((255 * (x + y)) // (2 * W), max=255)]
+    n2 = [(s >> 8) & 7, (s >> 12) & 7, (s >> 16) & 7]
+    n3 = [(s >> 8) & 255, (s >> 16) & 255, (s >> 24) & 255]
+    out = torch.empty((n_planes, h, w), dtype=torch.int32, device=device)
+    for c in range(3):
+        v = torch.where(kk == 2, (base[c] + n2[c]) % 256, base[c])
+        v = torch.where(kk == 3, n3[c], v)
+        out[c] = v.to(torch.int32)
+    if n_planes == 4:
+        frame = (x < W // 8) | (x >= W - W // 16) | (y < W // 16) | (y >= W - W // 8)
+        holes = (((x >> 7) + (y >> 7)) % 5) == 0
+        out[3] = torch.where(frame | holes, 0, 255).to(torch.int32)
+    return out
