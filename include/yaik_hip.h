@@ -139,6 +139,10 @@ int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, 
 const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
+/* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
+ * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches */
+int yk_selftest(yk_ctx* c, int which, int* result);
+
 /* ---- timing hooks for bench.py: HIP events on the handle's stream around the last yk_encode_tiles ---- */
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);
 

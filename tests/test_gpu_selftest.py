@@ -1,0 +1,37 @@
+"""Exhaustive on-device checks of the arithmetic shortcuts the kernels use, and corner-stream parity."""
+import ctypes as C
+
+import pytest
+
+from tests.images import edge_image, synth_planes
+from tests.parity import compare_encode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from yaik_amd.encoder import HipTileEncoder
+    e = HipTileEncoder(0)
+    yield e
+    e.close()
+
+
+def test_reciprocal_division_is_ieee_exact(hip):
+    from yaik_amd._lib import lib
+    res = C.c_int(-1)
+    assert lib().yk_selftest(hip._h, 0, C.byref(res)) == 0
+    assert res.value == 0, f"{res.value} of 65536 (minDiff, value) pairs differ from __fdiv_rn"
+
+
+CORNER_CASES = {
+    "synth256x4": lambda: synth_planes(256, n_planes=4), "synth512x3": lambda: synth_planes(512, n_planes=3),
+    "mixed128": lambda: edge_image(128, 128, "mixed"), "ramp200x136": lambda: edge_image(200, 136, "ramp"),
+    "smooth256": lambda: edge_image(256, 256, "smooth"), "twocolor128": lambda: edge_image(128, 128, "twocolor"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CORNER_CASES))
+def test_corner_streams_bit_exact(hip, oracle_built, case):
+    bad = compare_encode(CORNER_CASES[case](), hip, False, want_dst=False, check_corners=True)
+    assert not bad, bad

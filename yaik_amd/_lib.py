@@ -69,6 +69,7 @@ SIGNATURES = {
     "yk_decode_planes": (C.c_int, [vp, vp, vp, vp, sz]),
     "yk_decode_planes_device": (vp, [vp, szp]),
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
+    "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 

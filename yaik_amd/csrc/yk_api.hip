@@ -54,7 +54,7 @@ void yk_destroy(yk_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     yk_free_image(c);
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch);
+    F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;

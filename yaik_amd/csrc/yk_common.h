@@ -68,10 +68,12 @@ struct yk_ctx {
     uint8_t* cornerStream = nullptr; size_t cornerCap = 0;
     uint32_t* cornerScratch = nullptr; size_t cornerScratchElems = 0;
     bool cornersReady = false; int nextCornerPass = 0;
+    size_t cornerOff[7] = {}, cornerBytes[7] = {};
     // decode
     int dw = 0, dh = 0; uint8_t* dPlanes = nullptr; size_t dPlaneSize = 0;
     uint8_t* dMapRGB = nullptr; uint32_t* dLatticeOwner = nullptr; uint8_t* dTile4 = nullptr; size_t dTile4Size = 0;
     uint8_t* dScratch = nullptr; size_t dScratchBytes = 0;
+    uint8_t* dLoaded = nullptr;         // lattice point already popped from a colour stream (mapRGBMask)
     bool dSplit = false;
     // timing
     hipEvent_t ev[6] = {};

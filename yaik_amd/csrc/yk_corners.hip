@@ -1,4 +1,160 @@
-// placeholder until the corner-stream kernels land (next commit)
+// yk_corners.hip — the corner-colour streams of the gradient passes (`rgbStream`, encoder/EncoderContext.cpp:3783-3785,
+// emission :4113-4132, cross-pass de-duplication through `mappedRGB` :4001-4021).
+//
+// The reference emits, for every accepted tile in scan order, the corners TL,TR,BL,BR whose lattice point has not been
+// emitted by any earlier tile of this or an earlier pass.  That is a first-toucher problem:
+//   1. owner[lattice point] = min over all accepted tiles touching it of key = pass<<27 | bitIndex<<2 | corner
+//      (bitIndex = the tile's position in the swizzled bitmap = the reference's scan order `pos`)        -- atomicMin
+//   2. per pass: every bitmap word counts the corners its tiles own, an exclusive scan gives the byte offsets,
+//      and the owners write CompressF(Round6(v),250) for R,G,B.
+// All bitmaps stay on the device; only the finished streams are copied out.
 #include "yk_common.h"
-int yk_launch_corners(yk_ctx* c) { return yk_fail(c, YK_ERR_STATE, "corner streams not built yet"); }
-extern "C" int yk_gradient_corners(yk_ctx* c, int, uint8_t*, size_t, size_t*) { return yk_fail(c, YK_ERR_STATE, "corner streams not built yet"); }
+#include "yk_device.h"
+
+struct PassGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow; };
+
+__host__ __device__ static inline PassGeo yk_pass_geo(int pass, int w) {
+    const int sxs[7] = { 4, 4, 3, 3, 3, 2, 2 }, sys[7] = { 4, 3, 4, 3, 2, 3, 2 };
+    PassGeo g; g.sx = sxs[pass]; g.sy = sys[pass];
+    g.bigX = g.sx == 2 ? 32 : 64; g.bigY = g.sy == 2 ? 32 : 64;        // getSwizzleSize, include/YAIK_private.h:212-276
+    g.tilesPerRow = g.bigX >> g.sx;
+    g.bitCount = g.tilesPerRow * (g.bigY >> g.sy);
+    g.xBB = (w + g.bigX - 1) / g.bigX;
+    return g;
+}
+
+__device__ __forceinline__ void yk_tile_from_bit(const PassGeo& g, uint32_t pos, int& x, int& y) {
+    const uint32_t blk = pos / g.bitCount, t = pos % g.bitCount;
+    x = (int)(blk % g.xBB) * g.bigX + (int)(t % g.tilesPerRow) * (1 << g.sx);
+    y = (int)(blk / g.xBB) * g.bigY + (int)(t / g.tilesPerRow) * (1 << g.sy);
+}
+
+__global__ __launch_bounds__(256) void yk_corner_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, int pass, int w, int latW,
+                                                              uint32_t* __restrict__ owner) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= nWords) return;
+    uint32_t bits = bitmap[wi];
+    const PassGeo g = yk_pass_geo(pass, w);
+    while (bits) {
+        const int b = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t pos = (uint32_t)(wi * 32 + b);
+        int x, y; yk_tile_from_bit(g, pos, x, y);
+        const int lx = x >> 2, ly = y >> 2, dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+        const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
+        atomicMin(&owner[(size_t)ly * latW + lx], key | 0u);
+        atomicMin(&owner[(size_t)ly * latW + lx + dx], key | 1u);
+        atomicMin(&owner[(size_t)(ly + dy) * latW + lx], key | 2u);
+        atomicMin(&owner[(size_t)(ly + dy) * latW + lx + dx], key | 3u);
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, int pass, int w, int h, int latW,
+                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ wordCnt,
+                                                                const uint32_t* __restrict__ blockBase, const int32_t* const __restrict__ pR,
+                                                                const int32_t* const __restrict__ pG, const int32_t* const __restrict__ pB, int strideElems,
+                                                                uint8_t* __restrict__ out) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t wi = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t word = wi < nWords ? bitmap[wi] : 0u;
+    const PassGeo g = yk_pass_geo(pass, w);
+    const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+    uint32_t cnt = 0;
+    if (!EMIT) {
+        uint32_t bits = word;
+        while (bits) {
+            const int b = __ffs(bits) - 1; bits &= bits - 1;
+            const uint32_t pos = (uint32_t)(wi * 32 + b);
+            int x, y; yk_tile_from_bit(g, pos, x, y);
+            const int lx = x >> 2, ly = y >> 2;
+            const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
+            cnt += owner[(size_t)ly * latW + lx] == (key | 0u);
+            cnt += owner[(size_t)ly * latW + lx + dx] == (key | 1u);
+            cnt += owner[(size_t)(ly + dy) * latW + lx] == (key | 2u);
+            cnt += owner[(size_t)(ly + dy) * latW + lx + dx] == (key | 3u);
+        }
+        if (wi < nWords) wordCnt[wi] = cnt;
+        return;
+    }
+    cnt = wi < nWords ? wordCnt[wi] : 0u;
+    uint32_t tot;
+    uint32_t off = (blockBase[blockIdx.x] + yk_block_exscan(cnt, s_tmp, &tot)) * 3u;
+    uint32_t bits = word;
+    while (bits) {
+        const int b = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t pos = (uint32_t)(wi * 32 + b);
+        int x, y; yk_tile_from_bit(g, pos, x, y);
+        const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int lx = (x >> 2) + ((k & 1) ? dx : 0), ly = (y >> 2) + ((k & 2) ? dy : 0);
+            if (owner[(size_t)ly * latW + lx] == (key | (uint32_t)k)) {
+                const size_t src = (size_t)min(ly * 4, h - 1) * strideElems + min(lx * 4, w - 1);     // GetPixelValue clamp (:3853-3856)
+                const int v[3] = { pR[src], pG[src], pB[src] };
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
+                    out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
+                }
+                off += 3;
+            }
+        }
+    }
+}
+
+int yk_launch_corners(yk_ctx* c) {
+    if (c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "corner streams need a handle that owns the whole image (stripe lattice rows are shared)");
+    const int w = c->fullW, h = c->h;
+    const int latW = w / 4 + 1, latH = h / 4 + 1;
+    const size_t lat = (size_t)latW * latH;
+    if (!c->latticeOwner) { YK_HIP(c, hipMalloc(&c->latticeOwner, lat * 4)); c->latticeElems = lat; }
+    if (!c->cornerStream) { c->cornerCap = lat * 3 + 64; YK_HIP(c, hipMalloc(&c->cornerStream, c->cornerCap)); }
+    const size_t maxWords = (c->bitmapBytes[6] + 3) / 4 + 1;
+    const size_t nbMax = (maxWords + 1023) / 1024;
+    if (!c->cornerScratch) { c->cornerScratchElems = maxWords + nbMax + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
+    uint32_t* wordCnt = c->cornerScratch; uint32_t* blockBase = c->cornerScratch + maxWords; uint32_t* totalDev = blockBase + nbMax;
+    YK_HIP(c, hipMemsetAsync(c->latticeOwner, 0xFF, lat * 4, c->stream));
+    for (int p = 0; p < 7; p++) {
+        const size_t nWords = (c->bitmapBytes[p] + 3) / 4;      // bitmap allocations are padded by 16 bytes; pass 0 words may be half used
+        if (c->bitmapBytes[p] & 3) YK_HIP(c, hipMemsetAsync(c->bitmap[p] + c->bitmapBytes[p], 0, 4 - (c->bitmapBytes[p] & 3), c->stream));
+        hipLaunchKernelGGL(yk_corner_owner_kernel, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint32_t*>(c->bitmap[p]), nWords, p, w, latW, c->latticeOwner);
+    }
+    size_t off = 0;
+    for (int p = 0; p < 7; p++) {
+        const size_t nWords = (c->bitmapBytes[p] + 3) / 4;
+        const unsigned nb = (unsigned)((nWords + 1023) / 1024);
+        const uint32_t* bm = reinterpret_cast<const uint32_t*>(c->bitmap[p]);
+        hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
+                           (const uint32_t*)nullptr, c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr);
+        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3(nb), dim3(1024), 0, c->stream, wordCnt, nWords, blockBase);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockBase, (int)nb, totalDev);
+        hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
+                           blockBase, c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + off);
+        uint32_t total = 0;
+        YK_HIP(c, hipMemcpyAsync(&total, totalDev, 4, hipMemcpyDeviceToHost, c->stream));
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        c->cornerOff[p] = off; c->cornerBytes[p] = (size_t)total * 3;
+        off += (size_t)total * 3;
+        if (off > c->cornerCap) return yk_fail(c, YK_ERR_RANGE, "corner stream overflow");
+    }
+    YK_HIP(c, hipGetLastError());
+    c->cornersReady = true;
+    return YK_OK;
+}
+
+extern "C" int yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap, size_t* nBytes) {
+    if (!c || pass < 0 || pass >= 7) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
+    if (nBytes) *nBytes = c->cornerBytes[pass];
+    if (hostOut) {
+        if (cap < c->cornerBytes[pass]) return yk_fail(c, YK_ERR_RANGE, "corner buffer too small");
+        if (c->cornerBytes[pass]) {
+            YK_HIP(c, hipMemcpyAsync(hostOut, c->cornerStream + c->cornerOff[pass], c->cornerBytes[pass], hipMemcpyDeviceToHost, c->stream));
+            YK_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return YK_OK;
+}

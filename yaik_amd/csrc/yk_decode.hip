@@ -1,11 +1,320 @@
-// placeholder until the decode kernels land (next commit)
+// yk_decode.hip — gfx950 kernels for the per-tile decode loops behind YAIK_DecodeImage's chunk switch
+// (decoder/YAIK_API.cpp:731-1303):
+//
+//   yk_decode_gradient   a16  DecompressGradient16x16/16x8/8x16/8x8/8x4/4x8/4x4   (decoder/YAIK_Gradient.cpp:28..1418)
+//   yk_decode_1d         a17  Decompress1D x 3 planes                              (decoder/YAIK_3DTile.cpp:24-240)
+//   yk_decode_mask       a18  Decompress1BitTiled                                  (decoder/YAIK_Mipmap.cpp:23-154)
+//
+// HBM layout mirrors YAIK_Instance (include/YAIK_private.h:26-54): planeR|G|B u8 in 8x8 tiles (tile-major, 64 B/tile,
+// include/YAIK.h:205-224), the mapRGB corner lattice ((W/4+1) x (H/4+1) x 3 u8) and tile4x4Mask (1 bit per 4x4 cell).
+// The reference walks each bitmap sequentially and pops "not yet seen" corners off the colour stream; on the GPU the
+// stream offset of every tile is a prefix sum over the bitmap words of the corners each tile is the FIRST to touch
+// (first toucher by scan position = atomicMin of bitIndex<<2|corner), then all tiles of the pass render in parallel.
+// Passes are launched in call order, so a later, overlapping tile overwrites an earlier one exactly like the reference.
 #include "yk_common.h"
-extern "C" {
-int yk_decode_begin(yk_ctx* c, int, int) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
-int yk_decode_gradient(yk_ctx* c, int, int, const uint8_t*, size_t, const uint8_t*, size_t) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
-int yk_decode_1d(yk_ctx* c, const uint8_t*, size_t, const uint8_t*, size_t, int) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
-int yk_decode_mask(yk_ctx* c, const uint8_t*, int, int, uint8_t*, size_t) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
-int yk_decode_planes(yk_ctx* c, uint8_t*, uint8_t*, uint8_t*, size_t) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
-const uint8_t* yk_decode_planes_device(const yk_ctx*, size_t*) { return nullptr; }
-int yk_decode_tile4x4(yk_ctx* c, uint8_t*, size_t) { return yk_fail(c, YK_ERR_STATE, "decode not built yet"); }
+#include "yk_device.h"
+
+struct DPassGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow; };
+
+__host__ __device__ static inline DPassGeo yk_dpass_geo(int sx, int sy, int w) {
+    DPassGeo g; g.sx = sx; g.sy = sy;
+    g.bigX = sx == 2 ? 32 : 64; g.bigY = sy == 2 ? 32 : 64;            // getSwizzleSize, include/YAIK_private.h:212-276
+    g.tilesPerRow = g.bigX >> sx; g.bitCount = g.tilesPerRow * (g.bigY >> sy);
+    g.xBB = (w + g.bigX - 1) / g.bigX;
+    return g;
 }
+
+__device__ __forceinline__ void yk_dtile_from_bit(const DPassGeo& g, uint32_t pos, int& x, int& y) {
+    const uint32_t blk = pos / g.bitCount, t = pos % g.bitCount;
+    x = (int)(blk % g.xBB) * g.bigX + (int)(t % g.tilesPerRow) * (1 << g.sx);
+    y = (int)(blk / g.xBB) * g.bigY + (int)(t / g.tilesPerRow) * (1 << g.sy);
+}
+
+// phase 1: first toucher of every not-yet-loaded lattice point
+__global__ __launch_bounds__(256) void yk_dec_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
+                                                           const uint8_t* __restrict__ loaded, uint32_t* __restrict__ owner) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= nWords) return;
+    uint32_t bits = bitmap[wi];
+    const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+    while (bits) {
+        const int b = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t pos = (uint32_t)(wi * 32 + b);
+        int x, y; yk_dtile_from_bit(g, pos, x, y);
+        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
+            if (!loaded[li]) atomicMin(&owner[li], (pos << 2) | (uint32_t)k);
+        }
+    }
+}
+
+// phase 2 (EMIT=false): corners owned per bitmap word; phase 3 (EMIT=true): pop the colours into the lattice (:97-136)
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
+                                                             uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner, uint32_t* __restrict__ wordCnt,
+                                                             const uint32_t* __restrict__ blockBase, const uint8_t* __restrict__ rgb, size_t rgbBytes,
+                                                             uint8_t* __restrict__ mapRGB) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t wi = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t word = wi < nWords ? bitmap[wi] : 0u;
+    const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+    uint32_t off = 0;
+    if (EMIT) {
+        uint32_t tot;
+        off = (blockBase[blockIdx.x] + yk_block_exscan(wi < nWords ? wordCnt[wi] : 0u, s_tmp, &tot)) * 3u;
+    }
+    uint32_t cnt = 0, bits = word;
+    while (bits) {
+        const int b = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t pos = (uint32_t)(wi * 32 + b);
+        int x, y; yk_dtile_from_bit(g, pos, x, y);
+        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
+            if (owner[li] == ((pos << 2) | (uint32_t)k)) {
+                if (EMIT) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) mapRGB[li * 3 + c] = (off + c < rgbBytes) ? rgb[off + c] : 0;
+                    loaded[li] = 1;
+                    off += 3;
+                } else cnt++;
+            }
+        }
+    }
+    if (!EMIT && wi < nWords) wordCnt[wi] = cnt;
+}
+
+// phase 4: integer bilinear fill with truncation (:160-188, :762-781, :1382-1401) + tile4x4Mask marking.
+// One workgroup per bitmap word, its 256 threads share the tiles of the word.
+__global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
+                                                            const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                            uint32_t* __restrict__ tile4, int stride4) {
+    const size_t wi = blockIdx.x;
+    uint32_t bits = bitmap[wi];
+    if (!bits) return;
+    const int TX = 1 << g.sx, TY = 1 << g.sy, dx = TX >> 2, dy = TY >> 2, npx = TX * TY;
+    while (bits) {
+        const int b = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t pos = (uint32_t)(wi * 32 + b);
+        int x, y; yk_dtile_from_bit(g, pos, x, y);
+        if (x + TX > w || y + TY > h) continue;
+        const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
+        for (int e = threadIdx.x; e < npx * 3; e += 256) {
+            const int c = e / npx, p = e - c * npx, tx = p & (TX - 1), ty = p >> g.sx;
+            const int TL = mapRGB[l0 * 3 + c], TR = mapRGB[(l0 + dx) * 3 + c];
+            const int BL = mapRGB[(l0 + (size_t)dy * latW) * 3 + c], BR = mapRGB[(l0 + (size_t)dy * latW + dx) * 3 + c];
+            const int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
+            const int xx = x + tx, yy = y + ty;
+            planes[(size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7)] =
+                (uint8_t)((L * (TX - tx) + R * tx) >> (g.sx + g.sy));
+        }
+        // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953)
+        for (int e = threadIdx.x; e < dx * dy; e += 256) {
+            const int cx = (x >> 2) + (e % dx), cy = (y >> 2) + (e / dx);
+            const size_t byteIdx = (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
+            const uint32_t bit = (uint32_t)((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+            atomicOr(&tile4[byteIdx >> 2], 1u << (bit + 8 * (byteIdx & 3)));
+        }
+    }
+}
+
+// ---- 1-D range decode -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
+                                                              uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i >= T8) return;
+    const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
+    int q = tile4[(tx >> 1) + (size_t)ty * stride4];
+    q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;                                        // YAIK_3DTile.cpp:74-78
+    cntTiles[i] = q != 0xF;
+    cntPix[i] = 16u * (4u - (uint32_t)__popc(q));
+}
+
+__global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
+                                                        const uint32_t* __restrict__ cntTiles, const uint32_t* __restrict__ cntPix,
+                                                        const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
+                                                        const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
+                                                        const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
+                                                        uint8_t* __restrict__ planes, size_t planeSize) {
+    __shared__ uint32_t s_tmp[32];
+    const int p = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t tot;
+    const uint32_t et = yk_block_exscan(i < T8 ? cntTiles[i] : 0u, s_tmp, &tot);
+    const uint32_t ep = yk_block_exscan(i < T8 ? cntPix[i] : 0u, s_tmp, &tot);
+    if (i >= T8 || !cntTiles[i]) return;
+    const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
+    int q = tile4[(tx >> 1) + (size_t)ty * stride4];
+    q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;
+    size_t to = ((size_t)p * totals[0] + baseTiles[blockIdx.x] + et) * 3, po = (size_t)p * totals[1] + basePix[blockIdx.x] + ep;
+    if (to + 2 >= typeBytes) return;
+    const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
+    const int delta2 = ((delta * invRange) >> 8) + 1;                           // :66, :86
+    uint8_t* tile = planes + (size_t)p * planeSize + i * 64;
+    for (int half = 0; half < 2; half++) {
+        const bool left = !(q & 1), right = !(q & 2);
+        q >>= 2;
+        for (int r = 0; r < 4; r++) for (int cx = 0; cx < 8; cx++) {
+            if ((cx < 4 && !left) || (cx >= 4 && !right)) continue;
+            const int L = po < pixBytes ? pix[po] : 0; po++;
+            tile[(half * 4 + r) * 8 + cx] = (uint8_t)(L ? (base + (((L - 1) * delta2) >> 16)) : color0);   // :113-124
+        }
+    }
+}
+
+__global__ void yk_dec_mask_kernel(const uint8_t* __restrict__ bits, int bw, int bh, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bw * bh) return;
+    const int x = i % bw, y = i / bw;
+    const unsigned long long v = (bits[i >> 3] & (1 << (i & 7))) ? ~0ULL : 0ULL;     // YAIK_Mipmap.cpp:119-136
+    unsigned long long* A = out + (size_t)y * 4 * bw + 2 * x;
+    A[0] = v; A[1] = v; A[2 * bw] = v; A[2 * bw + 1] = v;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int yk_dec_scratch(yk_ctx* c, size_t bytes) {
+    if (c->dScratchBytes >= bytes) return YK_OK;
+    if (c->dScratch) { YK_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dScratch); c->dScratch = nullptr; }
+    YK_HIP(c, hipMalloc(&c->dScratch, bytes));
+    c->dScratchBytes = bytes;
+    return YK_OK;
+}
+
+extern "C" {
+
+int yk_decode_begin(yk_ctx* c, int w, int h) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (w < 16 || h < 16 || (w & 15) || (h & 15) || w > 32752 || h > 32752) return yk_fail(c, YK_ERR_BAD_ARG, "decode needs width/height multiples of 16");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dLoaded);
+    c->dw = w; c->dh = h;
+    const int tileW = w >> 3, tileH = h >> 3;
+    c->dPlaneSize = (size_t)tileW * tileH * 64;
+    const size_t lat = (size_t)(w / 4 + 1) * (h / 4 + 1);
+    const int stride4 = (w + 15) >> 4;
+    c->dTile4Size = (size_t)((stride4 << 2) * (((h + 7) >> 3) << 1)) >> 3;
+    YK_HIP(c, hipMalloc(&c->dPlanes, c->dPlaneSize * 3));
+    YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3));
+    YK_HIP(c, hipMalloc(&c->dLatticeOwner, lat * 4));
+    YK_HIP(c, hipMalloc(&c->dLoaded, lat));
+    YK_HIP(c, hipMalloc(&c->dTile4, ((c->dTile4Size + 3) & ~(size_t)3) + 4));
+    YK_HIP(c, hipMemsetAsync(c->dPlanes, 0, c->dPlaneSize * 3, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dMapRGB, 0, lat * 3, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dLoaded, 0, lat, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dTile4, 0, ((c->dTile4Size + 3) & ~(size_t)3) + 4, c->stream));
+    return YK_OK;
+}
+
+int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes) {
+    if (!c || !bitmap) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    static const int ok[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    bool found = false; for (auto& o : ok) found |= (o[0] == sx && o[1] == sy);
+    if (!found) return yk_fail(c, YK_ERR_BAD_ARG, "unsupported tile format");
+    YK_HIP(c, hipSetDevice(c->device));
+    const int w = c->dw, h = c->dh, latW = w / 4 + 1;
+    const size_t lat = (size_t)latW * (h / 4 + 1);
+    const DPassGeo g = yk_dpass_geo(sx, sy, w);
+    const size_t need = ((size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount) >> 3;
+    if (bitmapBytes < need) return yk_fail(c, YK_ERR_RANGE, "tile bitmap shorter than the image needs");
+    const size_t nWords = (need + 3) / 4, nb = (nWords + 1023) / 1024;
+    // scratch: [bitmap words][rgb][wordCnt][blockBase][total]
+    const size_t oB = 0, oR = oB + nWords * 4 + 16, oC = (oR + rgbBytes + 19) & ~(size_t)15, oBB = oC + nWords * 4, oT = oBB + nb * 4 + 16;
+    int rc = yk_dec_scratch(c, oT + 64); if (rc) return rc;
+    uint8_t* S = c->dScratch;
+    YK_HIP(c, hipMemsetAsync(S + oB, 0, nWords * 4, c->stream));
+    YK_HIP(c, hipMemcpyAsync(S + oB, bitmap, need, hipMemcpyHostToDevice, c->stream));
+    if (rgbBytes) YK_HIP(c, hipMemcpyAsync(S + oR, rgb, rgbBytes, hipMemcpyHostToDevice, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
+    const uint32_t* bm = reinterpret_cast<const uint32_t*>(S + oB);
+    uint32_t* wordCnt = reinterpret_cast<uint32_t*>(S + oC); uint32_t* blockBase = reinterpret_cast<uint32_t*>(S + oBB);
+    uint32_t* total = reinterpret_cast<uint32_t*>(S + oT);
+    hipLaunchKernelGGL(yk_dec_owner_kernel, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner);
+    hipLaunchKernelGGL(yk_dec_corner_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
+                       wordCnt, (const uint32_t*)nullptr, (const uint8_t*)nullptr, (size_t)0, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, wordCnt, nWords, blockBase);
+    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockBase, (int)nb, total);
+    hipLaunchKernelGGL(yk_dec_corner_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
+                       wordCnt, blockBase, S + oR, rgbBytes, c->dMapRGB);
+    hipLaunchKernelGGL(yk_dec_render_kernel, dim3((unsigned)nWords), dim3(256), 0, c->stream, bm, nWords, g, w, h, latW, c->dMapRGB, c->dPlanes, c->dPlaneSize,
+                       w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
+    YK_HIP(c, hipGetLastError());
+    YK_HIP(c, hipStreamSynchronize(c->stream));            // the host buffers may be reused by the caller
+    return YK_OK;
+}
+
+int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes, int compressionRange) {
+    if (!c || !typeStream || !pixStream || compressionRange <= 0) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    YK_HIP(c, hipSetDevice(c->device));
+    const int w = c->dw, h = c->dh, tilesW = w >> 3;
+    const size_t T8 = (size_t)tilesW * (h >> 3), nb = (T8 + 1023) / 1024;
+    const size_t oTy = 0, oPx = (oTy + typeBytes + 31) & ~(size_t)15, oCT = (oPx + pixBytes + 31) & ~(size_t)15, oCP = oCT + T8 * 4,
+                 oBT = oCP + T8 * 4, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16;
+    int rc = yk_dec_scratch(c, oTot + 64); if (rc) return rc;
+    uint8_t* S = c->dScratch;
+    YK_HIP(c, hipMemcpyAsync(S + oTy, typeStream, typeBytes, hipMemcpyHostToDevice, c->stream));
+    YK_HIP(c, hipMemcpyAsync(S + oPx, pixStream, pixBytes, hipMemcpyHostToDevice, c->stream));
+    uint32_t* cT = reinterpret_cast<uint32_t*>(S + oCT); uint32_t* cP = reinterpret_cast<uint32_t*>(S + oCP);
+    uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
+    hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP);
+    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
+    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
+    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
+    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
+    hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
+                       S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize);
+    YK_HIP(c, hipGetLastError());
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int bw, int bh, uint8_t* hostOut, size_t cap) {
+    if (!c || !bits || !hostOut || bw <= 0 || bh <= 0) return YK_ERR_BAD_ARG;
+    const size_t outBytes = (size_t)bw * bh * 32, inBytes = ((size_t)bw * bh + 7) / 8;
+    if (cap < outBytes) return yk_fail(c, YK_ERR_RANGE, "mask buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    const size_t oO = (inBytes + 31) & ~(size_t)15;
+    int rc = yk_dec_scratch(c, oO + outBytes + 64); if (rc) return rc;
+    YK_HIP(c, hipMemcpyAsync(c->dScratch, bits, inBytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(yk_dec_mask_kernel, dim3((unsigned)((bw * bh + 255) / 256)), dim3(256), 0, c->stream, c->dScratch, bw, bh,
+                       reinterpret_cast<unsigned long long*>(c->dScratch + oO));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->dScratch + oO, outBytes, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, size_t capEach) {
+    if (!c || !hostR || !hostG || !hostB) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    if (capEach < c->dPlaneSize) return yk_fail(c, YK_ERR_RANGE, "plane buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    uint8_t* dst[3] = { hostR, hostG, hostB };
+    for (int p = 0; p < 3; p++) YK_HIP(c, hipMemcpyAsync(dst[p], c->dPlanes + p * c->dPlaneSize, c->dPlaneSize, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize) {
+    if (!c || !c->dPlanes) return nullptr;
+    if (planeSize) *planeSize = c->dPlaneSize;
+    return c->dPlanes;
+}
+
+int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap) {
+    if (!c || !hostOut) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    if (cap < c->dTile4Size) return yk_fail(c, YK_ERR_RANGE, "tile4x4 buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->dTile4, c->dTile4Size, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+}  // extern "C"

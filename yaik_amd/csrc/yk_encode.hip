@@ -14,6 +14,7 @@
 // No MFMA: integer / byte work bounded by HBM streaming of 12-16 B/pixel.
 #include "yk_common.h"
 #include "yk_curves.h"
+#include "yk_device.h"
 
 __constant__ float c_curve[6][16] = YK_CURVE_TABLE;
 
@@ -24,34 +25,45 @@ __constant__ float c_curve[6][16] = YK_CURVE_TABLE;
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h, int y0,
                                                        uint8_t* __restrict__ keep, int mtW, int mtH, int32_t* __restrict__ bbox /*x0,y0,x1,y1*/) {
+    // grid-stride over 64x64 blocks: a wave that only issues four 16-byte loads is too short-lived to keep HBM busy,
+    // so each wave walks many blocks and keeps its bounding box in registers until the end.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bx = blockIdx.x, by = blockIdx.y;
-    const int mty = by * 4 + wave;
-    if (mty >= mtH) return;
-    const int gx = bx * 64 + (lane & 15) * 4;
-    int nz = 0;
+    const int nbx = (w + 63) >> 6, nby = (h + 63) >> 6;
+    int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
+    for (int blk = blockIdx.x; blk < nbx * nby; blk += gridDim.x) {
+        const int bx = blk % nbx, by = blk / nbx;
+        const int mty = by * 4 + wave;
+        if (mty >= mtH) continue;
+        const int gx = bx * 64 + (lane & 15) * 4;
+        int nz = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int gy = mty * 16 + k * 4 + (lane >> 4);
-        if (gx < w && gy < h) {
-            const int4 a = *reinterpret_cast<const int4*>(alpha + (size_t)gy * strideElems + gx);
-            nz |= a.x | a.y | a.z | a.w;
+        for (int k = 0; k < 4; k++) {
+            const int gy = mty * 16 + k * 4 + (lane >> 4);
+            if (gx < w && gy < h) {
+                const int4 a = *reinterpret_cast<const int4*>(alpha + (size_t)gy * strideElems + gx);
+                nz |= a.x | a.y | a.z | a.w;
+            }
+        }
+        const unsigned long long b = __ballot(nz != 0);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int mtx = bx * 4 + m;
+            if (mtx >= mtW) break;
+            const bool kept = (b & (0x000F000F000F000FULL << (4 * m))) != 0;
+            if (lane == 0) keep[mty * mtW + mtx] = kept ? 1 : 0;
+            if (kept) {
+                x0 = min(x0, mtx * 16); x1 = max(x1, mtx * 16 + 16);
+                gy0 = min(gy0, y0 + mty * 16); gy1 = max(gy1, y0 + mty * 16 + 16);
+            }
         }
     }
-    const unsigned long long b = __ballot(nz != 0);
-    int x0 = 9999999, x1 = -1;
-    bool any = false;
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int mtx = bx * 4 + m;
-        if (mtx >= mtW) break;
-        const bool kept = (b & (0x000F000F000F000FULL << (4 * m))) != 0;
-        if (lane == 0) keep[mty * mtW + mtx] = kept ? 1 : 0;
-        if (kept) { any = true; x0 = min(x0, mtx * 16); x1 = max(x1, mtx * 16 + 16); }
-    }
-    if (lane == 0 && any) {
-        atomicMin(&bbox[0], x0); atomicMax(&bbox[2], x1);
-        atomicMin(&bbox[1], y0 + mty * 16); atomicMax(&bbox[3], y0 + mty * 16 + 16);
+    if (lane == 0 && x1 >= 0) {
+        // min/max are monotone, so a (possibly stale) read that already beats our value makes the atomic unnecessary
+        // (a single address only sustains ~88 atomics/us).
+        if (__hip_atomic_load(&bbox[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > x0) atomicMin(&bbox[0], x0);
+        if (__hip_atomic_load(&bbox[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x1) atomicMax(&bbox[2], x1);
+        if (__hip_atomic_load(&bbox[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > gy0) atomicMin(&bbox[1], gy0);
+        if (__hip_atomic_load(&bbox[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gy1) atomicMax(&bbox[3], gy1);
     }
 }
 
@@ -223,8 +235,22 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
 
         // ---- a6: the seven passes in the shipped order (EncoderContext.cpp:9057-9093) -------------------------
         unsigned long long cov = 0ULL;                    // bit 4*cell = cell covered (mapSmoothTile != 0)
-        yk_grad_pass<4, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
-        if (cov != 0x1111111111111111ULL) {
+        // Necessary condition shared by all passes and all six variants: inside any tile the blend numerator S' is LINEAR in x,
+        // so for three horizontally adjacent pixels of one tile |b(x-1) - 2 b(x) + b(x+1)| <= 1 (floor effects), hence an
+        // accepted tile needs |c(x-1) - 2 c(x) + c(x+1)| <= 4*rejectFactor + 1 on every channel.  A lane's four pixels always
+        // lie in one tile, so a lane violating it kills every tile it belongs to; if all 64 lanes do, no pass can accept.
+        bool dead = false;
+        {
+            const int lim = 4 * P.rejectFactor + 1;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int c0 = cc[ch] >> 8, c1 = cc[3 + ch] >> 8, c2 = cc[6 + ch] >> 8, c3 = cc[9 + ch] >> 8;
+                dead |= (abs(c0 - 2 * c1 + c2) > lim) | (abs(c1 - 2 * c2 + c3) > lim);
+            }
+        }
+        const bool anyAlive = __ballot(!dead) != 0ULL;
+        if (anyAlive) yk_grad_pass<4, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
+        if (anyAlive && cov != 0x1111111111111111ULL) {
             yk_grad_pass<4, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
             yk_grad_pass<3, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
             yk_grad_pass<3, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
@@ -330,14 +356,23 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
                     }
                 }
             }
-            // per-pixel relative error terms (:884-886), IEEE division, handed to the chain lanes through LDS
+            // per-pixel relative error terms (:884-886), correctly rounded like the reference's divss, handed to the chain lanes
+            // through LDS.  One IEEE reciprocal per pixel, then a Markstein step per mode (yk_div_exact; all 256x256 operand
+            // pairs are checked against __fdiv_rn on the GPU by yk_selftest / tests/test_gpu_selftest.py).
+            float fv[4], rv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool on = valid && v[i] != 0;
+                fv[i] = (float)v[i];
+                rv[i] = on ? __fdiv_rn(1.0f, fv[i]) : 0.0f;       // r = 0 makes every term exactly +0 (skipped pixel)
+            }
 #pragma unroll
             for (int m = 0; m < 6; m++) {
                 float qv[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float md = (float)(int)(key[m][i] >> 4);
-                    qv[i] = (valid && v[i] != 0 && m >= P.startMode) ? __fdiv_rn(md, (float)v[i]) : 0.0f;
+                    qv[i] = (m >= P.startMode) ? yk_div_exact(md, fv[i], rv[i]) : 0.0f;
                 }
                 *reinterpret_cast<float4*>(&s_chain[wave][t8 * 6 + m][p0]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
             }
@@ -430,27 +465,6 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
 // ------------------------------------------------------------------------------------------------------------------
 #define YK_SCAN_TILE 1024
 
-__device__ __forceinline__ uint32_t yk_block_exscan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
-    // exclusive scan over the 1024 threads of a block
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
-    if (lane == 63) s_tmp[wave] = x;
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t t = lane < 16 ? s_tmp[lane] : 0;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { uint32_t y = __shfl_up(t, d); if (lane >= d) t += y; }
-        if (lane < 16) s_tmp[16 + lane] = t;
-    }
-    __syncthreads();
-    const uint32_t waveBase = wave ? s_tmp[16 + wave - 1] : 0;
-    *total = s_tmp[16 + 15];
-    __syncthreads();
-    return waveBase + x - v;
-}
-
 __global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restrict__ tileCount, size_t T8, uint32_t* __restrict__ blockSums, int nBlocks) {
     __shared__ uint32_t s_tmp[32];
     const int p = blockIdx.y;
@@ -528,7 +542,8 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
 int yk_launch_alpha(yk_ctx* c) {
     static const int32_t init[16] = { 0, 0, 0, 0, 1, 0, 0, 0, 9999999, 9999999, -1, -1, 0, 0, 0, 0 };
     YK_HIP(c, hipMemcpyAsync(c->bounds, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    dim3 grid((c->fullW + 63) / 64, (c->h + 63) / 64);
+    const int nBlocks = ((c->fullW + 63) / 64) * ((c->h + 63) / 64);
+    dim3 grid(nBlocks < 2048 ? nBlocks : 2048);
     hipLaunchKernelGGL(yk_alpha_kernel, grid, dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h, c->y0,
                        c->keep, c->mtW, c->mtH, c->bounds + 8);
     YK_HIP(c, hipGetLastError());
@@ -574,5 +589,30 @@ int yk_launch_pack(yk_ctx* c) {
     hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, c->tileDef, c->slots, T8, c->blockSums, nb,
                        c->defsOut, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
     YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// self-test hooks (run by tests/test_gpu_selftest.py): exhaustive checks of the arithmetic shortcuts used above
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void yk_selftest_div_kernel(int* mismatches) {
+    const int n = blockIdx.x, d = threadIdx.x + 1;           // n in 0..255, d in 1..256
+    const float fn = (float)n, fd = (float)d;
+    const float ref = __fdiv_rn(fn, fd);
+    const float got = yk_div_exact(fn, fd, __fdiv_rn(1.0f, fd));
+    if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1);
+}
+
+extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
+    if (!c || !result) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    int* d = nullptr;
+    YK_HIP(c, hipMalloc(&d, sizeof(int)));
+    YK_HIP(c, hipMemsetAsync(d, 0, sizeof(int), c->stream));
+    if (which == 0) hipLaunchKernelGGL(yk_selftest_div_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
+    YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
     return YK_OK;
 }

@@ -1,0 +1,66 @@
+"""Python plumbing over the decode half of the C-ABI (include/yaik_hip.h): the loops behind
+YAIK_DecodeImage's chunk switch (decoder/YAIK_API.cpp:731-1303), executed on the GPU.
+
+Method names follow the reference: DecompressGradient*, Decompress1D, Decompress1BitTiled.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import YaikError, lib
+from .encoder import _chk
+
+
+class HipTileDecoder:
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        rc = lib().yk_create(device, C.byref(h))
+        if rc != 0:
+            raise YaikError(f"yk_create failed ({rc}): no usable HIP device -- the product path has no CPU fallback")
+        self._h = h
+        self.w = self.h = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().yk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def begin(self, w: int, h: int):
+        self.w, self.h = w, h
+        _chk(self._h, lib().yk_decode_begin(self._h, w, h))
+
+    def decompress_gradient(self, sx: int, sy: int, bitmap: np.ndarray, rgb_dq: np.ndarray):
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        rgb_dq = np.ascontiguousarray(rgb_dq, dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_gradient(self._h, sx, sy, bitmap.ctypes.data, bitmap.size,
+                                               rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size))
+
+    def decompress_1d(self, type_stream: np.ndarray, pix_stream: np.ndarray, compression_range: int = 15):
+        t = np.ascontiguousarray(type_stream, dtype=np.uint8)
+        p = np.ascontiguousarray(pix_stream, dtype=np.uint8)
+        if t.size == 0 or p.size == 0:
+            return
+        _chk(self._h, lib().yk_decode_1d(self._h, t.ctypes.data, t.size, p.ctypes.data, p.size, compression_range))
+
+    def decompress_1bit_tiled(self, bits: np.ndarray, bw: int, bh: int) -> np.ndarray:
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        out = np.zeros(bw * bh * 32, dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_mask(self._h, bits.ctypes.data, bw, bh, out.ctypes.data, out.size))
+        return out
+
+    def planes(self) -> np.ndarray:
+        n = (self.w // 8) * (self.h // 8) * 64
+        out = np.zeros((3, n), dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_planes(self._h, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, n))
+        return out
+
+    def tile4x4(self) -> np.ndarray:
+        n = ((((self.w + 15) >> 4) << 2) * (((self.h + 7) >> 3) << 1)) >> 3
+        out = np.zeros(n, dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_tile4x4(self._h, out.ctypes.data, n))
+        return out
