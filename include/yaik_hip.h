@@ -112,6 +112,13 @@ const uint8_t*  yk_range_nibbles_device(const yk_ctx* c, int plane);
 int yk_range_dst(yk_ctx* c, int plane, int32_t* hostOut, size_t capElems);
 int yk_set_dst_fill(yk_ctx* c, int32_t fill);
 
+/* ---- a15  live 1-D range path:  3x EncoderContext::DynamicTileCompressor(stream, plane, mapSmoothTile[plane], debug)
+ * (EncoderContext.cpp:8398-8522, call sites :9451-9465) on what the gradient passes left uncovered.  Produces the two
+ * streams GenerateDynamicTileChunk hands to ZStd (:8524-8576): pixel bytes (planes R,G,B appended, 1 B per pixel) and the
+ * per-tile parameter bytes color0,minCol,delta (`streamType`, :8503-8505).  colorCompression1D = 255, rangeCompression1D = 15. */
+int yk_range1d_encode(yk_ctx* c);
+int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType);
+
 /* ---- tile-map export for the multi-GPU gather (new; the reference is single-process) -----------------------
  * Packs this handle's results into ONE caller-owned HBM buffer (device-to-device copies on the handle's stream) so
  * that a single RCCL gather can concatenate the per-stripe / per-frame tile maps.  Layout, every section padded to

@@ -1,0 +1,102 @@
+"""Recomputes, with the CPU oracle, the named blobs that oracle/ref_driver.cpp dumps from the unmodified reference,
+so that golden fixtures (tests/golden/*.npz, hashes.json) and live reference runs can be compared name by name."""
+import numpy as np
+
+from oracle.pyoracle import (PASSES, OracleDecoder, OracleEncoder, palette_decompress)
+
+# blobs whose bytes depend on uninitialised reference memory or that the fixtures do not keep
+SKIP = {"meta", "mip_chunk", "dec_mapRGB"}
+
+
+def oracle_blobs(planes: np.ndarray) -> dict:
+    n, h, w = planes.shape
+    out = {}
+    enc = OracleEncoder(planes)
+    if n == 4:
+        m = enc.mip_prefilter()
+        out["mip_bounds"] = np.array(list(m["bounds"]) + [16, m["remaining"]], dtype=np.int32).tobytes()
+        out["mip_mask"] = enc.state("mipmapMask").tobytes()
+        out["_mip_bitmap"] = m["bitmap"].tobytes()
+        out["_mip_tile_bbox"] = m["tile_bbox"].astype(np.int16).tobytes()
+        out["_mip_has_chunk"] = bytes([int(m["has_chunk"])])
+    counts, streams = [], []
+    for i, (sx, sy) in enumerate(PASSES):
+        cnt, bm, rgb = enc.fitting_quad_smooth(sx, sy)
+        counts.append(cnt)
+        out[f"grad_bitmap_{i}"] = bm.tobytes()
+        if cnt:
+            pal = enc.palette_compress(rgb)                       # same process-global code table as the reference
+            dq = palette_decompress(pal, rgb.size, 250)
+            out[f"grad_palette_{i}"] = pal.tobytes()
+        else:
+            dq = np.zeros(0, np.uint8)
+        out[f"grad_rgbdq_{i}"] = dq.tobytes()
+        streams.append((sx, sy, cnt, bm, dq))
+    out["grad_counts"] = np.array(counts, dtype=np.int32).tobytes()
+    out["smoothMap"] = enc.state("smoothMap").tobytes()
+    out["mipmapMask_post"] = enc.state("mipmapMask").tobytes()
+    out["bounds_post"] = enc.bounds().astype(np.int32).tobytes()
+    for p in range(3):
+        out[f"mapSmoothTile_{p}"] = enc.state("mapSmoothTile", p).tobytes()
+        out[f"preview_{p}"] = enc.state("preview", p).astype(np.int16).tobytes()
+    for m in range(2):
+        for p in range(3):
+            defs, nib, nn, dst = enc.dynamic_tile_encode(p, bool(m))
+            out[f"plnt_defs_{m}_{p}"] = defs.tobytes()
+            out[f"plnt_idx_{m}_{p}"] = nib.tobytes()
+            out[f"plnt_dst_{m}_{p}"] = dst.astype(np.int16).tobytes()
+    ends = []
+    for p in range(3):
+        _, dbg = enc.dynamic_tile_compressor(p)
+        out[f"d1_out_{p}"] = dbg.astype(np.int16).tobytes()
+        pix, typ = enc.streams_1d()
+        ends.append((pix.size, typ.size))
+    pix, typ = enc.streams_1d()
+    out["d1_pix"] = pix.tobytes()
+    out["d1_type"] = typ.tobytes()
+    out["d1_ends"] = np.array([e[0] for e in ends] + [e[1] for e in ends], dtype=np.int32).tobytes()
+    if w % 16 == 0 and h % 16 == 0:
+        dec = OracleDecoder(w, h)
+        for sx, sy, cnt, bm, dq in streams:
+            if cnt:
+                dec.gradient(sx, sy, bm, dq)
+        out["dec_planes_grad"] = dec.planes().tobytes()
+        out["dec_tile4x4"] = dec.tile4x4().tobytes()
+        out["dec_mapRGBMask"] = dec.map_rgb_mask().tobytes()
+        dec.split_masks()
+        tp, pp = dec.decode_1d(typ, pix)
+        out["dec_1d_consumed"] = np.array([tp, pp], dtype=np.int32).tobytes()
+        out["dec_planes_full"] = dec.planes().tobytes()
+    return out
+
+
+def parse_mip_chunk(chunk: bytes):
+    """'MIPM' chunk as written by MipPrefilter (EncoderContext.cpp:1367-1396): HeaderBase(8) + MipmapHeader(16) + bitmap.
+    MipmapHeader.streamSize is never initialised by the reference, so only bbox / level / bitmap are comparable."""
+    if not chunk:
+        return None
+    bbox = np.frombuffer(chunk[8:16], np.int16).copy()
+    level = chunk[21]
+    nbytes = (int(bbox[2]) * int(bbox[3]) + 7) // 8
+    return bbox, level, np.frombuffer(chunk[24:24 + nbytes], np.uint8).copy()
+
+
+def compare_with_reference(ref: dict, ours: dict, decode_ok: bool = True) -> list:
+    bad = []
+    for k, v in ref.items():
+        if k in SKIP or (not decode_ok and k.startswith("dec_")):
+            continue
+        if k not in ours:
+            bad.append(f"missing {k}")
+        elif bytes(v) != ours[k]:
+            bad.append(f"{k}: {len(v)} vs {len(ours[k])} bytes")
+    if "mip_chunk" in ref:
+        parsed = parse_mip_chunk(bytes(ref["mip_chunk"]))
+        has = ours["_mip_has_chunk"] == b"\x01"
+        if (parsed is not None) != has:
+            bad.append("mip chunk presence")
+        elif parsed is not None:
+            bbox, level, bm = parsed
+            if bbox.tobytes() != ours["_mip_tile_bbox"] or level != 4 or bm.tobytes() != ours["_mip_bitmap"]:
+                bad.append("mip chunk content")
+    return bad

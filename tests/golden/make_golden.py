@@ -1,0 +1,60 @@
+"""Generates the golden vectors under tests/golden/ from the UNMODIFIED reference (oracle/_ref/ref_driver, built by
+oracle/Makefile from the sources under /root/reference).  The reference ships no fixtures of its own, so
+these captured outputs are the parity anchor that travels with the repo; the reference itself never does.
+
+    python tests/golden/make_golden.py          # needs oracle/_ref/ref_driver (i.e. a checkout with /root/reference present)
+
+Fixtures are data only: inputs are regenerated from seeds (yaik_amd.synth / tests.images), outputs are the blobs the
+reference produced: small images keep every blob (npz, compressed), larger ones keep a SHA-256 per blob.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.refrun import have_ref, run_reference  # noqa: E402
+from tests.images import edge_image, synth_planes  # noqa: E402
+
+FULL = {   # name -> planes factory; every reference blob is stored
+    "synth64_rgb": lambda: synth_planes(64, n_planes=3),
+    "mixed128_rgba": lambda: edge_image(128, 128, "mixed", 4),
+    "twocolor64_rgb": lambda: edge_image(64, 64, "twocolor", 3),
+    "ramp72x40_rgb": lambda: edge_image(72, 40, "ramp", 3),
+    "synth256_rgba": lambda: synth_planes(256, n_planes=4),
+}
+HASHED = {  # name -> planes factory; SHA-256 per blob
+    "synth512_rgba": lambda: synth_planes(512, n_planes=4),
+    "synth1024_rgba": lambda: synth_planes(1024, n_planes=4),
+    "mixed208x144_rgb": lambda: edge_image(208, 144, "mixed", 3),
+}
+# blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
+DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_", "grad_palette_")
+
+
+def main():
+    if not have_ref():
+        print("oracle/_ref/ref_driver is missing: run `make -C oracle` on a machine that has /root/reference", file=sys.stderr)
+        return 1
+    for name, mk in FULL.items():
+        blobs = run_reference(mk())
+        keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if not k.startswith(DROP_PREFIX)}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, sum(v.size for v in keep.values()), "bytes raw")
+    hashes = {}
+    for name, mk in HASHED.items():
+        blobs = run_reference(mk())
+        hashes[name] = {k: hashlib.sha256(v).hexdigest() for k, v in blobs.items() if not k.startswith(DROP_PREFIX)}
+        hashes[name]["grad_counts_values"] = np.frombuffer(blobs["grad_counts"], np.int32).tolist()
+    with open(os.path.join(HERE, "hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1, sort_keys=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,100 @@
+"""CPU suite: the N > 1 path with world_size 2 on gloo.  Each rank produces the tile maps of its own frame (with the CPU
+oracle standing in for the GPU encode, which needs a device), packs them in yk_export_tile_maps' layout, and the ranks run
+exactly the collectives bench.py runs: the bbox all-reduce of the row-stripe layout and the ONE gather of tile maps."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.pyoracle import PASSES, OracleEncoder
+from tests.images import edge_image, synth_planes
+from yaik_amd import distributed as ykd
+
+
+def _frame(rank):
+    return synth_planes(256, n_planes=4, seed=12345 + rank) if rank == 0 else edge_image(256, 256, "mixed", 4, seed=rank)
+
+
+def _encode_on_oracle(planes):
+    enc = OracleEncoder(planes)
+    m = enc.mip_prefilter()
+    bitmaps = [enc.fitting_quad_smooth(sx, sy)[1] for sx, sy in PASSES]
+    mask = enc.state("mipmapMask")                      # after the passes: 0 also where gradient tiles landed, so use the pre-pass rule
+    n, h, w = planes.shape
+    a = planes[3].reshape(h // 16, 16, w // 16, 16)
+    keep = (a != 0).any(axis=(1, 3)).astype(np.uint8).ravel()
+    defs, nibs, nn = [], [], []
+    for p in range(3):
+        d, nb, n_, _ = enc.dynamic_tile_encode(p, False)
+        defs.append(d); nibs.append(nb); nn.append(n_)
+    del mask
+    return m, bitmaps, keep, defs, nibs, nn
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, bitmaps, keep, defs, nibs, nn = _encode_on_oracle(_frame(rank))
+        payload, sizes = ykd.pack_blob(bitmaps, keep, defs, nibs, nn)
+        blob = torch.from_numpy(payload.copy())
+        # the row-stripe layout's only other exchange: image-wide kept-tile bbox
+        stripe_box = np.array([16 * (rank + 1), 32 * (rank + 1), 200 - 8 * rank, 240 - 16 * rank], dtype=np.int32)
+        gb = ykd.allreduce_bbox(stripe_box, dist, torch.device("cpu"))
+        assert gb.tolist() == [16, 32, 200, 240]
+        got = ykd.gather_tile_maps(blob, payload.size, sizes, dist, dst=0)
+        if rank == 0:
+            assert got is not None and len(got) == world
+            for r, (sz, pl) in enumerate(got):
+                want = _encode_on_oracle(_frame(r))
+                parts = ykd.split_blob(sz, pl)
+                for i in range(7):
+                    assert np.array_equal(parts["bitmaps"][i], want[1][i]), (r, i)
+                assert np.array_equal(parts["keep"], want[2])
+                for p in range(3):
+                    assert np.array_equal(parts["defs"][p], want[3][p])
+                    assert np.array_equal(parts["nibbles"][p], want[4][p])
+                    assert parts["n_nibbles"][p] == want[5][p]
+        else:
+            assert got is None
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_of_tile_maps(oracle_built):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_pack_split_roundtrip():
+    rng = np.random.default_rng(5)
+    bitmaps = [rng.integers(0, 256, n, dtype=np.uint8) for n in (2, 4, 4, 8, 16, 16, 32)]
+    keep = rng.integers(0, 2, 37, dtype=np.uint8)
+    defs = [rng.integers(0, 65536, n).astype(np.uint16) for n in (3, 0, 9)]
+    nn = [7, 0, 18]
+    nibs = [rng.integers(0, 256, (n + 1) // 2, dtype=np.uint8) for n in nn]
+    payload, sizes = ykd.pack_blob(bitmaps, keep, defs, nibs, nn)
+    assert payload.size % 16 == 0 and sizes[14] == payload.size
+    parts = ykd.split_blob(sizes, payload)
+    assert all(np.array_equal(a, b) for a, b in zip(parts["bitmaps"], bitmaps))
+    assert np.array_equal(parts["keep"], keep)
+    assert all(np.array_equal(a, b) for a, b in zip(parts["defs"], defs))
+    assert all(np.array_equal(a, b) for a, b in zip(parts["nibbles"], nibs))

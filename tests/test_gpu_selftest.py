@@ -35,3 +35,26 @@ CORNER_CASES = {
 def test_corner_streams_bit_exact(hip, oracle_built, case):
     bad = compare_encode(CORNER_CASES[case](), hip, False, want_dst=False, check_corners=True)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["synth256x4", "synth512x3", "mixed128", "ramp200x136", "twocolor128"])
+def test_live_1d_range_path_bit_exact(hip, oracle_built, case):
+    """a15: 3x DynamicTileCompressor streams (pixel bytes + color0/minCol/delta) vs the oracle."""
+    import numpy as np
+    from oracle.pyoracle import PASSES, OracleEncoder
+    planes = CORNER_CASES[case]()
+    ora = OracleEncoder(planes)
+    if planes.shape[0] == 4:
+        ora.mip_prefilter()
+    for sx, sy in PASSES:
+        ora.fitting_quad_smooth(sx, sy)
+    for p in range(3):
+        ora.dynamic_tile_compressor(p)
+    opix, otyp = ora.streams_1d()
+    hip.set_image(planes)
+    if planes.shape[0] == 4:
+        hip.mip_prefilter()
+    hip.encode(3, False, False)
+    pix, typ = hip.dynamic_tile_compressor()
+    assert np.array_equal(typ, otyp)
+    assert np.array_equal(pix, opix)

@@ -1,0 +1,125 @@
+"""CPU suite: host-side logic, and that the C-ABI library loads and exports every symbol include/yaik_hip.h declares
+(no compute calls: there is no GPU here, and the product path must refuse to run without one)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "yaik_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(yk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from yaik_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = C.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == declared, (set(declared) ^ set(_lib.SIGNATURES))
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: without a HIP device the handle cannot even be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from yaik_amd._lib import YaikError
+    from yaik_amd.encoder import HipTileEncoder
+    with pytest.raises(YaikError):
+        HipTileEncoder(0)
+
+
+def test_product_sources_never_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "yaik_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.replace("checked against the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_curve_constants_match_glibc_powf(oracle_built):
+    """yk_curves.h (hex floats baked into the kernels) == the constants DynamicTile::buildTable derives with powf."""
+    text = open(os.path.join(ROOT, "yaik_amd", "csrc", "yk_curves.h")).read()
+    rows = re.findall(r"/\* (\w+) \*/ \{([^}]*)\}", text)
+    table = {name: [float.fromhex(x.strip().rstrip("f")) for x in body.split(",")] for name, body in rows}
+    ref = np.zeros(48, dtype=np.float32)
+    oracle_built.lib().yko_curve_constants(ref.ctypes.data)
+    assert np.array_equal(np.array(table["exp4"], np.float32), ref[0:16])
+    assert np.array_equal(np.array(table["log4"], np.float32), ref[16:32])
+    assert np.array_equal(np.array(table["exp3"][:8], np.float32), ref[32:40])
+    assert np.array_equal(np.array(table["log3"][:8], np.float32), ref[40:48])
+    lin4 = (np.arange(16, dtype=np.float32) / np.float32(15.0)).astype(np.float32)
+    lin3 = (np.arange(8, dtype=np.float32) / np.float32(7.0)).astype(np.float32)
+    assert np.array_equal(np.array(table["lin4"], np.float32), lin4)
+    assert np.array_equal(np.array(table["lin3"][:8], np.float32), lin3)
+
+
+def test_blend_reformulation_is_exact():
+    """The kernels test D = S' - 256*cur instead of the reference's 1024*1024-scaled blend (EncoderContext.cpp:3929-3991).
+    Exhaustive over all weights and a dense sample of corner values: blendCO == S'>>8 and blendC == (S'+127)>>8."""
+    rng = np.random.default_rng(0)
+    for T in (4, 8, 16):
+        wts = 1024 - np.arange(T) * (1024 // T)
+        lF, tF = np.meshgrid(wts, wts)
+        for _ in range(200):
+            tl, tr, bl, br = rng.integers(0, 256, 4)
+            for c in ((tl, tr, bl, br), (0, 255, 255, 0), (255, 255, 255, 255), (255, 0, 0, 255)):
+                a, b, c2, d = [int(v) for v in c]
+                S = (a * lF + b * (1024 - lF)) * tF + (c2 * lF + d * (1024 - lF)) * (1024 - tF)
+                blendC, blendCO = (S + (1 << 19) - 1) // (1 << 20), S // (1 << 20)
+                lx, wy = lF // 64, tF // 64
+                Sp = (a * lx + b * (16 - lx)) * wy + (c2 * lx + d * (16 - lx)) * (16 - wy)
+                assert Sp.max() <= 65280
+                assert np.array_equal(blendCO, Sp >> 8) and np.array_equal(blendC, (Sp + 127) >> 8)
+
+
+def test_synth_generators_agree():
+    import torch
+    from yaik_amd.synth import synth_planes, synth_planes_torch
+    for w, h, n, seed in ((64, 64, 4, 12345), (256, 128, 3, 7), (512, 512, 4, 12346)):
+        assert np.array_equal(synth_planes(w, h, n_planes=n, seed=seed), synth_planes_torch(w, h, n_planes=n, seed=seed, device="cpu").numpy())
+    assert not torch.cuda.is_available() or True
+
+
+def test_stripe_partition_and_stream_concatenation():
+    from yaik_amd import distributed as ykd
+    for full_h, world in ((16384, 8), (8192, 8), (4096, 3), (2048, 5), (64, 4), (200 * 8, 7)):
+        rows = [ykd.stripe_rows(full_h, world, r) for r in range(world)]
+        y = 0
+        for y0, h, halo in rows:
+            assert y0 == y and y0 % 64 == 0
+            y += h
+            if h:
+                assert halo == (1 if y0 + h < full_h else 0)
+                assert h % 64 == 0 or y0 + h == full_h
+        assert y == full_h
+    assert ykd.combine_bboxes([[9999999, 9999999, -1, -1], [32, 64, 200, 128], [16, 256, 100, 300]]).tolist() == [16, 64, 200, 300]
+    # nibble streams of stripes concatenate into the image-wide stream even across odd boundaries
+    rng = np.random.default_rng(1)
+    parts, counts, allnib = [], [], []
+    for n in (5, 0, 8, 3, 1):
+        nib = rng.integers(0, 16, n).astype(np.uint8)
+        allnib.append(nib)
+        packed = np.zeros((n + 1) // 2, np.uint8)
+        for i, v in enumerate(nib):
+            packed[i >> 1] |= v << ((i & 1) * 4)
+        parts.append(packed); counts.append(n)
+    out, total = ykd.concat_nibble_streams(parts, counts)
+    flat = np.concatenate(allnib)
+    assert total == flat.size
+    want = np.zeros((flat.size + 1) // 2, np.uint8)
+    for i, v in enumerate(flat):
+        want[i >> 1] |= v << ((i & 1) * 4)
+    assert np.array_equal(out, want)

@@ -1,0 +1,29 @@
+"""CPU suite: live comparison of the oracle restatement with the unmodified reference (oracle/_ref/ref_driver).
+Skipped where the reference build is absent (e.g. a checkout without /root/reference); the golden-vector test covers that case."""
+import pytest
+
+from oracle.refrun import have_ref, run_reference
+from tests.blobs import compare_with_reference, oracle_blobs
+from tests.images import edge_image, synth_planes
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref/ref_driver not built (needs /root/reference)")
+
+CASES = {
+    "synth128_rgb": lambda: synth_planes(128, n_planes=3),
+    "synth256_rgba": lambda: synth_planes(256, n_planes=4),
+    "noise64_rgb": lambda: edge_image(64, 64, "noise", 3),
+    "flat128_rgba": lambda: edge_image(128, 128, "flat", 4),
+    "smooth128_rgba": lambda: edge_image(128, 128, "smooth", 4),
+    "white128_rgb": lambda: edge_image(128, 128, "white", 3),
+    "dark64_rgb": lambda: edge_image(64, 64, "dark", 3),
+    "twocolor256_rgba": lambda: edge_image(256, 256, "twocolor", 4),
+    "mixed200x136_rgb": lambda: edge_image(200, 136, "mixed", 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_equals_reference(oracle_built, name):
+    planes = CASES[name]()
+    n, h, w = planes.shape
+    bad = compare_with_reference(run_reference(planes), oracle_blobs(planes), decode_ok=(w % 16 == 0 and h % 16 == 0))
+    assert not bad, bad

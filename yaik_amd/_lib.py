@@ -60,6 +60,8 @@ SIGNATURES = {
     "yk_range_nibbles_device": (vp, [vp, C.c_int]),
     "yk_range_dst": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_set_dst_fill": (C.c_int, [vp, C.c_int32]),
+    "yk_range1d_encode": (C.c_int, [vp]),
+    "yk_range1d_streams": (C.c_int, [vp, vp, sz, szp, vp, sz, szp]),
     "yk_export_capacity": (sz, [vp]),
     "yk_export_tile_maps": (C.c_int, [vp, vp, sz, vp]),
     "yk_decode_begin": (C.c_int, [vp, C.c_int, C.c_int]),

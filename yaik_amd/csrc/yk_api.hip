@@ -21,6 +21,7 @@ static void yk_free_image(yk_ctx* c) {
     for (int i = 0; i < 3; i++) F(c->dst[i]);
     F(c->blockSums); F(c->totals); F(c->defsOut); F(c->nibOut);
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch);
+    F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
 }
 
@@ -263,7 +264,7 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     YK_HIP(c, hipEventRecord(c->ev[3], c->stream));
     rc = yk_launch_pack(c); if (rc) return rc;
     YK_HIP(c, hipEventRecord(c->ev[4], c->stream));
-    c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0;
+    c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 

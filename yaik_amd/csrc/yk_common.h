@@ -69,6 +69,9 @@ struct yk_ctx {
     uint32_t* cornerScratch = nullptr; size_t cornerScratchElems = 0;
     bool cornersReady = false; int nextCornerPass = 0;
     size_t cornerOff[7] = {}, cornerBytes[7] = {};
+    // live 1-D range path (a15)
+    uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
+    uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;
     // decode
     int dw = 0, dh = 0; uint8_t* dPlanes = nullptr; size_t dPlaneSize = 0;
     uint8_t* dMapRGB = nullptr; uint32_t* dLatticeOwner = nullptr; uint8_t* dTile4 = nullptr; size_t dTile4Size = 0;

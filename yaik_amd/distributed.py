@@ -65,6 +65,32 @@ def gather_tile_maps(blob, nbytes: int, sizes: np.ndarray, dist, dst: int = 0):
     return None
 
 
+def pack_blob(bitmaps, keep, defs, nibbles, n_nibbles) -> tuple[np.ndarray, np.ndarray]:
+    """Host-side twin of yk_export_tile_maps' layout (sections padded to 16 bytes); returns (payload uint8, sizes[15])."""
+    sizes = np.zeros(15, dtype=np.uint64)
+    chunks = []
+
+    def put(a):
+        b = np.ascontiguousarray(a).view(np.uint8).ravel()
+        chunks.append(b)
+        pad = (-b.size) & 15
+        if pad:
+            chunks.append(np.zeros(pad, np.uint8))
+    for i in range(7):
+        sizes[i] = bitmaps[i].size
+        put(bitmaps[i])
+    sizes[7] = keep.size
+    put(keep)
+    for p in range(3):
+        sizes[8 + 2 * p] = defs[p].size
+        sizes[9 + 2 * p] = n_nibbles[p]
+        put(np.asarray(defs[p], dtype=np.uint16))
+        put(np.asarray(nibbles[p], dtype=np.uint8)[: (n_nibbles[p] + 1) // 2])
+    payload = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    sizes[14] = payload.size
+    return payload, sizes
+
+
 def split_blob(sizes: np.ndarray, payload) -> dict:
     """Inverse of yk_export_tile_maps' layout: dict of numpy arrays from one rank's payload (CPU uint8 array/tensor)."""
     buf = payload.cpu().numpy() if hasattr(payload, "cpu") else np.asarray(payload, dtype=np.uint8)

@@ -88,7 +88,7 @@ class HipTileEncoder:
             _chk(self._h, lib().yk_alpha_finish(self._h, g.ctypes.data))
 
     def mip_prefilter(self) -> dict:
-        """Whole-image MipPrefilter: reject + finish + results (mirrors oracle.pyoracle.OracleEncoder.mip_prefilter)."""
+        """Whole-image EncoderContext::MipPrefilter: reject + finish + results."""
         if self.n == 4:
             self.alpha_reject()
             self.alpha_finish(None)
@@ -155,6 +155,18 @@ class HipTileEncoder:
         out = np.zeros((self.h, self.w), dtype=np.int32)
         _chk(self._h, lib().yk_range_dst(self._h, plane, out.ctypes.data, out.size))
         return out
+
+    # ---- 3x DynamicTileCompressor (live 1-D range path, '1DTL') -----------------------------------------
+    def dynamic_tile_compressor(self):
+        """Returns (pix_stream, type_stream) exactly as GenerateDynamicTileChunk receives them."""
+        L = lib()
+        _chk(self._h, L.yk_range1d_encode(self._h))
+        npx, nty = C.c_size_t(), C.c_size_t()
+        _chk(self._h, L.yk_range1d_streams(self._h, None, 0, C.byref(npx), None, 0, C.byref(nty)))
+        pix = np.zeros(npx.value, dtype=np.uint8); typ = np.zeros(nty.value, dtype=np.uint8)
+        _chk(self._h, L.yk_range1d_streams(self._h, pix.ctypes.data if pix.size else None, pix.size, None,
+                                            typ.ctypes.data if typ.size else None, typ.size, None))
+        return pix, typ
 
     def export_capacity(self) -> int:
         return int(lib().yk_export_capacity(self._h))
