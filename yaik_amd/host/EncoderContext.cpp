@@ -1,0 +1,144 @@
+// Host side of the drop-in `EncoderContext` for the tile hot path: thin caller of the C-ABI (include/yaik_hip.h).
+// Mirrors the reference's call contract (encoder/EncoderContext.cpp:1227-1427, 2784-2797, 3710-4363, 4365-4602, 8398-8522);
+// every pixel is processed by the HIP kernels, nothing is computed here.
+#include "EncoderContext.h"
+#include <climits>
+#include "../../include/yaik_hip.h"
+
+static const int kPass[7][2] = { {4, 4}, {4, 3}, {3, 4}, {3, 3}, {3, 2}, {2, 3}, {2, 2} };      // EncoderContext.cpp:9057-9093
+
+EncoderContext::EncoderContext()
+    : colorCompressionQuad(250), colorCompressionLUT3D(250), colorCompression1D(255), rangeCompression1D(15),
+      mipMapTileSize(16), boundX0(0), boundY0(0), boundX1(0), boundY1(0), remainingPixels(0),
+      dumpImage(false), evaluateLUT(false), evaluateLUT2D(false), outFile(nullptr), device(0),
+      original(nullptr), ctx(nullptr), bound(false), alphaDone(false), encoded(false), enc3(false), encDst(false), oneDReady(false),
+      encReject(3), nextPass(0), nNibbles(0), cursor1d(0), mipHasChunk(false) {}
+
+EncoderContext::~EncoderContext() { Release(); }
+
+bool EncoderContext::fail(const char* what) {
+    err = what;
+    if (ctx) { const char* e = yk_last_error(ctx); if (e && *e) { err += ": "; err += e; } }
+    printf("ERR %s\n", err.c_str());                    // the reference reports with printf and carries on (kassert, :24-28)
+    return false;
+}
+
+void EncoderContext::Release() {
+    if (ctx) { yk_destroy(ctx); ctx = nullptr; }
+    if (original) { delete original; original = nullptr; }
+    bound = alphaDone = encoded = oneDReady = false;
+}
+
+bool EncoderContext::SetImageToEncode(Image* newImage) {
+    if (original) delete original;
+    original = newImage;
+    bound = alphaDone = encoded = oneDReady = false; nextPass = 0;
+    if (!original) return false;
+    if (!ctx && yk_create(device, &ctx) != YK_OK) return fail("no usable HIP device (this path has no CPU fallback)");
+    const int w = original->GetWidth(), h = original->GetHeight(), n = original->HasAlpha() ? 4 : 3;
+    if (yk_set_image(ctx, w, h, n, 0, h, 0) != YK_OK) return fail("yk_set_image");
+    const int32_t* p[4] = { nullptr, nullptr, nullptr, nullptr };
+    for (int i = 0; i < n; i++) p[i] = original->GetPlane(i)->GetPixels();
+    if (yk_upload_planes(ctx, p, w) != YK_OK) return fail("yk_upload_planes");
+    bound = true;
+    return true;
+}
+
+void EncoderContext::PrepareQuadSmooth() {}
+
+void EncoderContext::CheckMipmapMask() {
+    // the reference lazily creates an all-255 mask and full-image bounds when MipPrefilter did not run (:2784-2794)
+    if (!alphaDone && original) { boundX0 = 0; boundY0 = 0; boundX1 = original->GetWidth(); boundY1 = original->GetHeight(); }
+}
+
+void EncoderContext::MipPrefilter(bool /*active*/) {
+    if (!bound) { fail("MipPrefilter: SetImageToEncode first"); return; }
+    mipBitmap.clear(); mipHasChunk = false;
+    if (original->HasAlpha()) {
+        if (yk_alpha_reject(ctx) != YK_OK || yk_alpha_finish(ctx, nullptr) != YK_OK) { fail("alpha reject"); return; }
+    }
+    int32_t b[4], tb[4]; int has = 0, rem = 0;
+    if (yk_alpha_result(ctx, b, &has, &rem, tb) != YK_OK) { fail("yk_alpha_result"); return; }
+    boundX0 = b[0]; boundY0 = b[1]; boundX1 = b[2]; boundY1 = b[3]; remainingPixels = rem; mipMapTileSize = 16; mipHasChunk = has != 0;
+    if (has) {
+        mipBitmap.resize(((size_t)tb[2] * tb[3] + 7) / 8 + 8);
+        size_t nb = 0;
+        if (yk_alpha_bitmap(ctx, mipBitmap.data(), mipBitmap.size(), &nb) != YK_OK) { fail("yk_alpha_bitmap"); return; }
+        mipBitmap.resize(nb);
+    }
+    alphaDone = true; encoded = false; nextPass = 0;
+}
+
+bool EncoderContext::ensureEncoded(int rejectFactor, bool mode3, bool wantDst) {
+    if (encoded && encReject == rejectFactor && enc3 == mode3 && (encDst || !wantDst)) return true;
+    if (original->HasAlpha() && !alphaDone) MipPrefilter(true);          // the reference's order: MipPrefilter precedes the tile passes
+    else CheckMipmapMask();
+    if (wantDst) yk_set_dst_fill(ctx, INT_MIN);
+    if (yk_encode_tiles(ctx, rejectFactor, mode3 ? 1 : 0, wantDst ? 1 : 0) != YK_OK) return fail("yk_encode_tiles");
+    encoded = true; encReject = rejectFactor; enc3 = mode3; encDst = wantDst; oneDReady = false;
+    return true;
+}
+
+int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* /*testOutput*/, bool useYCoCg,
+                                      int tileBitSizeX, int tileBitSizeY) {
+    if (!bound) { fail("FittingQuadSmooth: SetImageToEncode first"); return 0; }
+    if (a != original->GetPlane(0) || b != original->GetPlane(1) || c != original->GetPlane(2) || useYCoCg) {
+        fail("FittingQuadSmooth: only the full RGB pass (planes 0,1,2 of the image) is on this path"); return 0;
+    }
+    int pass = -1;
+    for (int i = 0; i < 7; i++) if (kPass[i][0] == tileBitSizeX && kPass[i][1] == tileBitSizeY) pass = i;
+    if (pass < 0 || pass != nextPass % 7) { fail("FittingQuadSmooth: passes must follow the shipped order 16x16,16x8,8x16,8x8,8x4,4x8,4x4"); return 0; }
+    if (pass == 0) encoded = false;                                       // a new sequence re-encodes (planes may have changed)
+    if (!ensureEncoded(rejectFactor, enc3, false)) return 0;
+    nextPass = pass + 1;
+    gradBitmap.resize(yk_gradient_bitmap_bytes(ctx, pass));
+    if (yk_gradient_bitmap(ctx, pass, gradBitmap.data(), gradBitmap.size()) != YK_OK) { fail("yk_gradient_bitmap"); return 0; }
+    size_t nb = 0;
+    const size_t cap = (size_t)(original->GetWidth() / 4 + 1) * (original->GetHeight() / 4 + 2) * 3 + 16;
+    gradRgb.resize(cap);
+    if (yk_gradient_corners(ctx, pass, gradRgb.data(), cap, &nb) != YK_OK) { fail("yk_gradient_corners"); return 0; }
+    gradRgb.resize(nb);
+    int tiles = 0;
+    for (u8 v : gradBitmap) tiles += __builtin_popcount(v);               // TileDone (:4362)
+    return tiles;
+}
+
+int EncoderContext::DynamicTileEncode(bool mode3BitOnly, Plane* plane, Plane* dst, bool isCo, bool isCg, bool isHalfX, bool isHalfY) {
+    if (!bound) { fail("DynamicTileEncode: SetImageToEncode first"); return 0; }
+    if (isCo || isCg || isHalfX || isHalfY) { fail("DynamicTileEncode: only full-resolution RGB planes are on this path"); return 0; }
+    int p = -1;
+    for (int i = 0; i < 3; i++) if (plane == original->GetPlane(i)) p = i;
+    if (p < 0) { fail("DynamicTileEncode: plane must be plane 0..2 of the image"); return 0; }
+    if (!ensureEncoded(encoded ? encReject : 3, mode3BitOnly, dst != nullptr)) return 0;
+    size_t nd = 0, nn = 0;
+    if (yk_range_sizes(ctx, p, &nd, &nn) != YK_OK) { fail("yk_range_sizes"); return 0; }
+    tileDefs.assign(nd, 0); tileIdx.assign((nn + 1) / 2, 0); nNibbles = nn;
+    if (yk_range_streams(ctx, p, tileDefs.data(), nd, tileIdx.data(), tileIdx.size()) != YK_OK) { fail("yk_range_streams"); return 0; }
+    if (dst) {                                                             // decoded values land in dst where a pixel was coded (:4448-4457)
+        const size_t n = (size_t)original->GetWidth() * original->GetHeight();
+        std::vector<int32_t> tmp(n);
+        if (yk_range_dst(ctx, p, tmp.data(), n) != YK_OK) { fail("yk_range_dst"); return 0; }
+        int* d = dst->GetPixels();
+        for (size_t i = 0; i < n; i++) if (tmp[i] != INT_MIN) d[i] = tmp[i];
+    }
+    return 0;                                                              // the reference returns layerSize, which it never updates (:4407,:4601)
+}
+
+u8* EncoderContext::DynamicTileCompressor(u8* stream, Plane* src, Plane* /*map*/, Plane* /*debug*/) {
+    if (!bound || !stream) { fail("DynamicTileCompressor: SetImageToEncode first"); return stream; }
+    int p = -1;
+    for (int i = 0; i < 3; i++) if (src == original->GetPlane(i)) p = i;
+    if (p < 0) { fail("DynamicTileCompressor: src must be plane 0..2 of the image"); return stream; }
+    if (!ensureEncoded(encoded ? encReject : 3, enc3, false)) return stream;
+    if (!oneDReady) {
+        if (yk_range1d_encode(ctx) != YK_OK) { fail("yk_range1d_encode"); return stream; }
+        size_t np = 0, nt = 0;
+        yk_range1d_streams(ctx, nullptr, 0, &np, nullptr, 0, &nt);
+        pix1d.resize(np); type1d.resize(nt);
+        if (yk_range1d_streams(ctx, pix1d.data(), np, nullptr, type1d.data(), nt, nullptr) != YK_OK) { fail("yk_range1d_streams"); return stream; }
+        oneDReady = true;
+    }
+    const size_t per = pix1d.size() / 3;                                   // coverage is shared by the three planes
+    memcpy(stream, pix1d.data() + per * p, per);
+    return stream + per;
+}

@@ -1,0 +1,67 @@
+// Drop-in mirror of the hot-path part of the reference's `EncoderContext` (encoder/EncoderContext.h:183-370 in KLab/YAIK):
+// same method names, argument meaning and call order for MipPrefilter -> 7x FittingQuadSmooth -> DynamicTileEncode x3
+// (-> DynamicTileCompressor x3), executed on an MI355X through the C-ABI of include/yaik_hip.h.
+//
+// Differences a caller sees (all consequences of "the entropy stage stays on host cores, outside this path"):
+//   * the passes do not fwrite chunks to `outFile`; the raw streams each pass hands to ZStd / PaletteCompressor in the
+//     reference are exposed through the Last*() accessors instead (bitmap, corner stream, tile defs, nibble stream);
+//   * the seven FittingQuadSmooth calls must come in the shipped order (4,4)(4,3)(3,4)(3,3)(3,2)(2,3)(2,2) with the image's
+//     planes 0,1,2 (EncoderContext.cpp:9057-9093): the first one launches the fused kernel, the others return its cached results;
+//   * errors follow the reference's convention (message on stdout, neutral return value) plus LastError().
+// The methods are public here: this class is the surface of the path, not of Convert().
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "framework.h"
+
+struct yk_ctx;
+
+struct EncoderContext {
+public:
+    EncoderContext();
+    ~EncoderContext();
+
+    // same tunables as the reference constructor defaults (EncoderContext.h:185-228)
+    int colorCompressionQuad, colorCompressionLUT3D, colorCompression1D, rangeCompression1D;
+    // mipmap-mask bounding box in pixels + bookkeeping the range quantiser reads (EncoderContext.h:246-253)
+    int mipMapTileSize, boundX0, boundY0, boundX1, boundY1, remainingPixels;
+    bool dumpImage, evaluateLUT, evaluateLUT2D;
+    FILE* outFile;                                      // kept for source compatibility; never written by this path
+
+    bool SetImageToEncode(Image* newImage);             // takes ownership, deletes the previous image (EncoderContext.cpp:1227-1233)
+    void Release();
+
+    void CheckMipmapMask();                             // EncoderContext.cpp:2784
+    void PrepareQuadSmooth();                           // empty in the reference too (:2796)
+    void MipPrefilter(bool active);                     // :1257
+    int  FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* testOutput, bool useYCoCg,
+                           int tileBitSizeX, int tileBitSizeY);                           // :3710, returns TileDone
+    int  DynamicTileEncode(bool mode3BitOnly, Plane* plane, Plane* dst, bool isCo, bool isCg, bool isHalfX, bool isHalfY);   // :4365
+    u8*  DynamicTileCompressor(u8* stream, Plane* src, Plane* map, Plane* debug);         // :8398, returns the advanced cursor
+
+    // raw streams of the last call of each kind (what the reference compresses and writes, before entropy coding)
+    const std::vector<u8>&  LastGradientBitmap() const { return gradBitmap; }             // pFillBitMap (:3775)
+    const std::vector<u8>&  LastGradientRGBStream() const { return gradRgb; }             // rgbStream (:3783)
+    const std::vector<u16>& LastTileDefs() const { return tileDefs; }                     // streamTileDef (:4419)
+    const std::vector<u8>&  LastTileIndexStream() const { return tileIdx; }               // streamTileIdx (:4421), closed to a byte
+    size_t                  LastTileIndexCount() const { return nNibbles; }
+    const std::vector<u8>&  MipmapBitmap() const { return mipBitmap; }                    // 'MIPM' payload (:1317-1327)
+    bool                    MipmapHasChunk() const { return mipHasChunk; }
+    const std::vector<u8>&  TileTypeStream1D() const { return type1d; }                   // streamType (:8217)
+    const char*             LastError() const { return err.c_str(); }
+    int                     device;                                                        // HIP device ordinal, set before SetImageToEncode
+
+private:
+    bool ensureEncoded(int rejectFactor, bool mode3, bool wantDst);
+    bool fail(const char* what);
+    Image* original;
+    yk_ctx* ctx;
+    bool bound, alphaDone, encoded, enc3, encDst, oneDReady;
+    int encReject, nextPass;
+    std::vector<u8> gradBitmap, gradRgb, tileIdx, mipBitmap, pix1d, type1d;
+    std::vector<u16> tileDefs;
+    size_t nNibbles, cursor1d;
+    bool mipHasChunk;
+    std::string err;
+};
