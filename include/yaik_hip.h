@@ -149,6 +149,9 @@ int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
  * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches */
 int yk_selftest(yk_ctx* c, int which, int* result);
+/* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
+ * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums */
+int yk_set_ablation(yk_ctx* c, int flags);
 
 /* ---- timing hooks for bench.py: HIP events on the handle's stream around the last yk_encode_tiles ---- */
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);

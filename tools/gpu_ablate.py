@@ -1,0 +1,30 @@
+"""Timing-only ablation of yk_encode_kernel on the GPU box: which phase costs what (results are wrong while flags != 0)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yaik_amd._lib import lib
+from yaik_amd.encoder import HipTileEncoder
+from yaik_amd.synth import synth_planes_torch
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+planes = synth_planes_torch(W, n_planes=4, device="cuda")
+enc = HipTileEncoder(0)
+enc.set_image(planes)
+enc.alpha_reject(); enc.alpha_finish(None)
+names = {0: "full", 1: "no range", 2: "no gradient", 3: "load+stage only", 4: "no LUT search", 8: "no error sums", 12: "no search, no sums"}
+for flags, name in names.items():
+    lib().yk_set_ablation(enc._h, flags)
+    for _ in range(2):
+        enc.encode(3, False, False)
+    tot = 0.0
+    for _ in range(5):
+        enc.encode(3, False, False)
+        tot += enc.kernel_ms()["encode"]
+    print(f"ablate={flags:2d} {name:22s} encode kernel {tot/5:.4f} ms", flush=True)
+lib().yk_set_ablation(enc._h, 0)
+for m3 in (False, True):
+    tot = 0.0
+    for _ in range(5):
+        enc.encode(3, m3, False)
+        tot += enc.kernel_ms()["encode"]
+    print(f"mode3={m3} encode kernel {tot/5:.4f} ms")

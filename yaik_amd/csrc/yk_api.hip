@@ -239,6 +239,8 @@ int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes) {
 }
 
 // ---- fused encode ------------------------------------------------------------------------------------
+int yk_set_ablation(yk_ctx* c, int flags) { if (!c) return YK_ERR_BAD_ARG; c->ablate = flags; return YK_OK; }
+
 int yk_set_dst_fill(yk_ctx* c, int32_t fill) { if (!c) return YK_ERR_BAD_ARG; c->dstFill = fill; return YK_OK; }
 
 int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) {

@@ -19,6 +19,7 @@ struct YkEncodeParams {
     int y0;                 // first owned row in full-image coordinates
     int fullH;
     int rejectFactor, startMode, wantDst;
+    int ablate;             // timing-only ablation switches (yk_set_ablation); 0 in every product run
     // alpha / bounds (device memory, written by the alpha kernels)
     const uint8_t* keep;    // per 16x16 macro-tile keep flag of this stripe, nullptr = no alpha plane
     const int32_t* bounds;  // [0..3] boundX0,Y0,X1,Y1 (full-image pixels), [4] discardRejects
@@ -81,6 +82,7 @@ struct yk_ctx {
     // timing
     hipEvent_t ev[6] = {};
     float msEncode = 0, msAlpha = 0, msPack = 0;
+    int ablate = 0;
 };
 
 int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);

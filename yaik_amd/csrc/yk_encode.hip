@@ -172,32 +172,63 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
     // ---- stage the clamped 65x65 block (Plane::GetPixelValue clamp, encoder/framework.h:116-121) -----------------
     if (tid < 24) s_bm[tid] = 0;
     {
+        // all global loads of the block are issued before the first one is consumed (12 x 16 B + halo per thread in flight)
         const int g4 = (tid & 15) * 4, r0 = tid >> 4;
         const int gx = BX * 64 + g4;
-        for (int r = r0; r < YK_LROWS; r += 16) {
-            const int gy = min(BY * 64 + r, P.hAvail - 1);
-            uint32_t o0, o1, o2, o3;
-            if (gx + 3 < w) {
+        const bool inX = gx + 3 < w;
+        int4 R[4], G[4], B[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int gy = min(BY * 64 + r0 + 16 * k, P.hAvail - 1);
+            if (inX) {
                 const size_t off = (size_t)gy * P.strideElems + gx;
-                const int4 R = *reinterpret_cast<const int4*>(P.plane[0] + off);
-                const int4 G = *reinterpret_cast<const int4*>(P.plane[1] + off);
-                const int4 B = *reinterpret_cast<const int4*>(P.plane[2] + off);
-                o0 = (uint32_t)R.x | ((uint32_t)G.x << 8) | ((uint32_t)B.x << 16);
-                o1 = (uint32_t)R.y | ((uint32_t)G.y << 8) | ((uint32_t)B.y << 16);
-                o2 = (uint32_t)R.z | ((uint32_t)G.z << 8) | ((uint32_t)B.z << 16);
-                o3 = (uint32_t)R.w | ((uint32_t)G.w << 8) | ((uint32_t)B.w << 16);
+                R[k] = *reinterpret_cast<const int4*>(P.plane[0] + off);
+                G[k] = *reinterpret_cast<const int4*>(P.plane[1] + off);
+                B[k] = *reinterpret_cast<const int4*>(P.plane[2] + off);
             } else {
                 const size_t off = (size_t)gy * P.strideElems + (w - 1);
-                o0 = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
-                o1 = o2 = o3 = o0;
+                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                R[k] = make_int4(r, r, r, r); G[k] = make_int4(gg, gg, gg, gg); B[k] = make_int4(b, b, b, b);
             }
-            *reinterpret_cast<uint4*>(&s_pix[r * YK_LSTRIDE + g4]) = make_uint4(o0, o1, o2, o3);
         }
-        if (tid < YK_LROWS) {      // right halo column
-            const int gy = min(BY * 64 + tid, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
+        // bottom halo row (LDS row 64): threads 0..15; right halo column: threads 64..128
+        int4 Rb = make_int4(0, 0, 0, 0), Gb = Rb, Bb = Rb;
+        if (tid < 16) {
+            const int gy = min(BY * 64 + 64, P.hAvail - 1);
+            if (inX) {
+                const size_t off = (size_t)gy * P.strideElems + gx;
+                Rb = *reinterpret_cast<const int4*>(P.plane[0] + off);
+                Gb = *reinterpret_cast<const int4*>(P.plane[1] + off);
+                Bb = *reinterpret_cast<const int4*>(P.plane[2] + off);
+            } else {
+                const size_t off = (size_t)gy * P.strideElems + (w - 1);
+                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                Rb = make_int4(r, r, r, r); Gb = make_int4(gg, gg, gg, gg); Bb = make_int4(b, b, b, b);
+            }
+        }
+        uint32_t hcol = 0;
+        const int hr = tid - 64;
+        if (hr >= 0 && hr < YK_LROWS) {
+            const int gy = min(BY * 64 + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
             const size_t off = (size_t)gy * P.strideElems + gxh;
-            s_pix[tid * YK_LSTRIDE + 64] = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
+            hcol = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 o = make_uint4((uint32_t)R[k].x | ((uint32_t)G[k].x << 8) | ((uint32_t)B[k].x << 16),
+                                       (uint32_t)R[k].y | ((uint32_t)G[k].y << 8) | ((uint32_t)B[k].y << 16),
+                                       (uint32_t)R[k].z | ((uint32_t)G[k].z << 8) | ((uint32_t)B[k].z << 16),
+                                       (uint32_t)R[k].w | ((uint32_t)G[k].w << 8) | ((uint32_t)B[k].w << 16));
+            *reinterpret_cast<uint4*>(&s_pix[(r0 + 16 * k) * YK_LSTRIDE + g4]) = o;
+        }
+        if (tid < 16) {
+            const uint4 o = make_uint4((uint32_t)Rb.x | ((uint32_t)Gb.x << 8) | ((uint32_t)Bb.x << 16),
+                                       (uint32_t)Rb.y | ((uint32_t)Gb.y << 8) | ((uint32_t)Bb.y << 16),
+                                       (uint32_t)Rb.z | ((uint32_t)Gb.z << 8) | ((uint32_t)Bb.z << 16),
+                                       (uint32_t)Rb.w | ((uint32_t)Gb.w << 8) | ((uint32_t)Bb.w << 16));
+            *reinterpret_cast<uint4*>(&s_pix[64 * YK_LSTRIDE + g4]) = o;
+        }
+        if (hr >= 0 && hr < YK_LROWS) s_pix[hr * YK_LSTRIDE + 64] = hcol;
     }
     __syncthreads();
 
@@ -248,7 +279,7 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
                 dead |= (abs(c0 - 2 * c1 + c2) > lim) | (abs(c1 - 2 * c2 + c3) > lim);
             }
         }
-        const bool anyAlive = __ballot(!dead) != 0ULL;
+        const bool anyAlive = (__ballot(!dead) != 0ULL) && !(P.ablate & 2);
         if (anyAlive) yk_grad_pass<4, 4>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
         if (anyAlive && cov != 0x1111111111111111ULL) {
             yk_grad_pass<4, 3>(s_pix, lbase, g, cc, cov, gx0, gy0, w, h, P.rejectFactor, s_bm, bx0, by0);
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
         const size_t T8 = (size_t)P.tilesW * P.tilesH;
         const unsigned long long anyValid = __ballot(valid);
 
-        if (anyValid == 0ULL) {
+        if (anyValid == 0ULL || (P.ablate & 1)) {
             if (jt == 0 && tileIn) {
 #pragma unroll
                 for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
@@ -317,7 +348,11 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
             const int BN = (base * 224) / 63;
             const int d8 = max(diff, 32);
             const int scale = 223 - BN;
-            const int dist = ((d8 - 32) * 127 + (scale - 1)) / scale;
+            // C division by `scale` (truncating).  scale is -1 (base 63) or 3..223 and the numerator is < 2^15, so the quotient
+            // is floor((n + 0.5) * rcp(scale)) with a 1-ulp reciprocal: the nearest integer boundary is >= 0.5/223 away
+            // while the error is < 0.002 (exhaustively checked by yk_selftest 1).
+            const int dnum = (d8 - 32) * 127 + (scale - 1);
+            const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
             const int rangeDecode = (dist * scale) / 127 + 32;
             const float Rf = (float)rangeDecode, BNf = (float)BN;
             // lane jt of the tile builds entry jt of every curve; stored pre-shifted (<<4) so that one v_sad_u32 yields
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
                 const uint32_t* lw = reinterpret_cast<const uint32_t*>(lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8));
 #pragma unroll
                 for (int i = 0; i < 4; i++) key[m][i] = 0xFFFFFFFFu;
-                if (m >= P.startMode) {
+                if (m >= P.startMode && !(P.ablate & 4)) {
 #pragma unroll
                     for (int k = 0; k < cnt / 2; k++) {
                         const uint32_t wv = lw[k];
@@ -566,7 +601,7 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst)
     YkEncodeParams P;
     for (int i = 0; i < 4; i++) P.plane[i] = c->plane[i];
     P.strideElems = c->strideElems; P.w = c->fullW; P.h = c->h; P.hAvail = c->h + c->halo; P.y0 = c->y0; P.fullH = c->fullH;
-    P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst;
+    P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst; P.ablate = c->ablate;
     P.keep = (c->nPlanes == 4) ? c->keep : nullptr;
     P.bounds = (c->nPlanes == 4) ? c->bounds : nullptr;
     for (int i = 0; i < 7; i++) P.bitmap[i] = c->bitmap[i];
@@ -603,6 +638,15 @@ __global__ void yk_selftest_div_kernel(int* mismatches) {
     if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1);
 }
 
+__global__ void yk_selftest_scale_kernel(int* mismatches) {
+    const int scale = blockIdx.x + 1, d8 = threadIdx.x;        // scale 1..256 (superset of 3..223), d8 32..255
+    if (d8 < 32) return;
+    const int dnum = (d8 - 32) * 127 + (scale - 1);
+    const int ref = dnum / scale;
+    const int got = __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
+    if (ref != got) atomicAdd(mismatches, 1);
+}
+
 extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     if (!c || !result) return YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));
@@ -610,6 +654,7 @@ extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     YK_HIP(c, hipMalloc(&d, sizeof(int)));
     YK_HIP(c, hipMemsetAsync(d, 0, sizeof(int), c->stream));
     if (which == 0) hipLaunchKernelGGL(yk_selftest_div_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 1) hipLaunchKernelGGL(yk_selftest_scale_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
     YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
