@@ -144,6 +144,10 @@ int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int tileBBoxW, int tileBBoxH,
 /* 8x8-tiled u8 planes exactly as YAIK_SCustomDataSource hands them to imageBuilderFunc (include/YAIK.h:205-224) */
 int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, size_t capEach);
 const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
+/* internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191): de-tile into interleaved rows at outputImageStride.
+ * hostAlpha == NULL -> RGB, 3 B/pixel, byte-identical to the reference.  With a linear 8-bit alpha plane (strideA bytes per
+ * row) the output is RGBA 4 B/pixel as include/YAIK.h documents; the reference's own RGBA branch is broken (:53-60). */
+int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA);
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------

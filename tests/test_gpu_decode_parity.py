@@ -64,6 +64,13 @@ def test_decode_matches_oracle(dec, oracle_built, kind, w, h):
     mse = float(np.mean(err ** 2))
     psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
     assert psnr > 30.0, psnr
+    # a20 default image builder: interleaved RGB rows at outputImageStride == numpy de-tile of the planes
+    img = dec.image(stride=w * 3 + 8)
+    want = np.stack([detile(gp[c], w, h) for c in range(3)], axis=-1).reshape(h, w * 3)
+    assert np.array_equal(img[:, : w * 3], want) and not img[:, w * 3:].any()
+    alpha = (np.arange(h * w, dtype=np.int64).reshape(h, w) % 251).astype(np.uint8)
+    rgba = dec.image(alpha=alpha).reshape(h, w, 4)
+    assert np.array_equal(rgba[..., :3], want.reshape(h, w, 3)) and np.array_equal(rgba[..., 3], alpha)
 
 
 @pytest.mark.parametrize("size", [256, 1024])

@@ -174,6 +174,20 @@ __global__ void yk_dec_mask_kernel(const uint8_t* __restrict__ bits, int bw, int
     A[0] = v; A[1] = v; A[2 * bw] = v; A[2 * bw + 1] = v;
 }
 
+// a20: the default image builder (decoder/YAIK_DefaultCallback.cpp:24-191): 8x8-tiled planes -> interleaved RGB rows at
+// outputImageStride.  With an alpha plane the reference never advances past the alpha byte (:53-60) and produces
+// 3-byte-strided garbage; this kernel writes proper RGBA (4 B/pixel) instead, which is what YAIK.h documents.
+__global__ __launch_bounds__(256) void yk_dec_detile_kernel(const uint8_t* __restrict__ planes, size_t planeSize, int tileW, int w, int h,
+                                                            const uint8_t* __restrict__ alpha, int strideA, uint8_t* __restrict__ out, size_t stride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t ti = ((size_t)(y >> 3) * tileW + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7);
+    const int bpp = alpha ? 4 : 3;
+    uint8_t* o = out + (size_t)y * stride + (size_t)x * bpp;
+    o[0] = planes[ti]; o[1] = planes[planeSize + ti]; o[2] = planes[2 * planeSize + ti];
+    if (alpha) o[3] = alpha[(size_t)y * strideA + x];
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int yk_dec_scratch(yk_ctx* c, size_t bytes) {
     if (c->dScratchBytes >= bytes) return YK_OK;
@@ -297,6 +311,24 @@ int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, 
     YK_HIP(c, hipSetDevice(c->device));
     uint8_t* dst[3] = { hostR, hostG, hostB };
     for (int p = 0; p < 3; p++) YK_HIP(c, hipMemcpyAsync(dst[p], c->dPlanes + p * c->dPlaneSize, c->dPlaneSize, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA) {
+    if (!c || !hostOut) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    const int w = c->dw, h = c->dh, bpp = hostAlpha ? 4 : 3;
+    if (outputImageStride < (size_t)w * bpp || (hostAlpha && strideA < w)) return yk_fail(c, YK_ERR_BAD_ARG, "output stride too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    const size_t outBytes = outputImageStride * h, aBytes = hostAlpha ? (size_t)strideA * h : 0, oA = (outBytes + 31) & ~(size_t)15;
+    int rc = yk_dec_scratch(c, oA + aBytes + 64); if (rc) return rc;
+    if (outputImageStride != (size_t)w * bpp) YK_HIP(c, hipMemsetAsync(c->dScratch, 0, outBytes, c->stream));   // row padding
+    if (hostAlpha) YK_HIP(c, hipMemcpyAsync(c->dScratch + oA, hostAlpha, aBytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
+                       hostAlpha ? c->dScratch + oA : (const uint8_t*)nullptr, strideA, c->dScratch, outputImageStride);
+    YK_HIP(c, hipGetLastError());
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->dScratch, outBytes, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
 }

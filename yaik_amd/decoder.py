@@ -59,6 +59,16 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_decode_planes(self._h, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, n))
         return out
 
+    def image(self, alpha: np.ndarray | None = None, stride: int | None = None) -> np.ndarray:
+        """internal_imageBuilderFunc: interleaved RGB ([h, stride] bytes, 3 B/pixel) or RGBA when an alpha plane is given."""
+        bpp = 4 if alpha is not None else 3
+        stride = stride or self.w * bpp
+        out = np.zeros((self.h, stride), dtype=np.uint8)
+        a = np.ascontiguousarray(alpha, dtype=np.uint8) if alpha is not None else None
+        _chk(self._h, lib().yk_decode_output(self._h, out.ctypes.data, stride, a.ctypes.data if a is not None else None,
+                                             a.shape[1] if a is not None else 0))
+        return out
+
     def tile4x4(self) -> np.ndarray:
         n = ((((self.w + 15) >> 4) << 2) * (((self.h + 7) >> 3) << 1)) >> 3
         out = np.zeros(n, dtype=np.uint8)

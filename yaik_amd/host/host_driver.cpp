@@ -1,6 +1,6 @@
 // Small C++ program written the way a YAIK maintainer would drive the reference's EncoderContext for this path
-// (compare oracle/ref_driver.cpp, which does the same against the unmodified reference): same call sequence, same
-// method names, but linked against the MI355X drop-in.  tests/test_gpu_host_mirror.py compares its output with the oracle.
+// (encoder/ImageEncoder.cpp:158-213 / EncoderContext::Convert): same call sequence, same method names, but linked against
+// the MI355X drop-in.  tests/test_gpu_host_mirror.py checks its output blob by blob.
 //
 // usage: host_driver <in.bin> <out.blobs> [mode3BitOnly]
 #include <cstdio>
