@@ -156,6 +156,9 @@ int yk_selftest(yk_ctx* c, int which, int* result);
 /* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
  * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums */
 int yk_set_ablation(yk_ctx* c, int flags);
+/* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = lane per 4x4 cell, 1 = lane per pixel row.
+ * Both produce identical results; kept selectable for A/B timing and as a cross-check in the tests. */
+int yk_set_kernel_version(yk_ctx* c, int version);
 
 /* ---- timing hooks for bench.py: HIP events on the handle's stream around the last yk_encode_tiles ---- */
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);

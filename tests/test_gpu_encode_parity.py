@@ -9,10 +9,13 @@ from tests.parity import compare_encode
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def hip():
+@pytest.fixture(scope="module", params=[2, 1], ids=["kernel_v2", "kernel_v1"])
+def hip(request):
+    """Both implementations of the fused kernel (lane per 4x4 cell / lane per pixel row) must match the oracle."""
+    from yaik_amd._lib import lib
     from yaik_amd.encoder import HipTileEncoder
     e = HipTileEncoder(0)
+    assert lib().yk_set_kernel_version(e._h, request.param) == 0
     yield e
     e.close()
 
@@ -29,3 +32,22 @@ def test_synth_bit_exact(hip, oracle_built, size, npl, m3):
 def test_edge_images_bit_exact(hip, oracle_built, kind, wh, npl):
     bad = compare_encode(edge_image(wh[0], wh[1], kind, npl), hip, False)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["synth256x4", "mixed128x4", "twocolor128", "noise64"])
+def test_exact_resummation_path_bit_exact(oracle_built, case):
+    """kernel v2 screens the mode-selection sums in tree order and falls back to the reference's sequential order only
+    for ambiguous tiles; flag 16 forces that fallback for every tile, and the result must still be bit-exact."""
+    from yaik_amd._lib import lib
+    from yaik_amd.encoder import HipTileEncoder
+    planes = {"synth256x4": lambda: synth_planes(256, n_planes=4), "mixed128x4": lambda: edge_image(128, 128, "mixed", 4),
+              "twocolor128": lambda: edge_image(128, 128, "twocolor", 3), "noise64": lambda: edge_image(64, 64, "noise", 3)}[case]()
+    e = HipTileEncoder(0)
+    try:
+        lib().yk_set_kernel_version(e._h, 2)
+        lib().yk_set_ablation(e._h, 16)
+        for m3 in (False, True):
+            bad = compare_encode(planes, e, m3)
+            assert not bad, bad
+    finally:
+        e.close()

@@ -1,4 +1,4 @@
-"""Timing-only ablation of yk_encode_kernel on the GPU box: which phase costs what (results are wrong while flags != 0)."""
+"""Timing-only ablation of the fused kernels on the GPU box: which phase costs what (results are wrong while flags != 0)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,20 +11,21 @@ planes = synth_planes_torch(W, n_planes=4, device="cuda")
 enc = HipTileEncoder(0)
 enc.set_image(planes)
 enc.alpha_reject(); enc.alpha_finish(None)
-names = {0: "full", 1: "no range", 2: "no gradient", 3: "load+stage only", 4: "no LUT search", 8: "no error sums", 12: "no search, no sums"}
-for flags, name in names.items():
-    lib().yk_set_ablation(enc._h, flags)
-    for _ in range(2):
-        enc.encode(3, False, False)
+names = {0: "full", 1: "no range", 2: "no gradient", 3: "load+stage only", 4: "no LUT search"}
+for ver in (1, 2):
+    lib().yk_set_kernel_version(enc._h, ver)
+    for flags, name in names.items():
+        lib().yk_set_ablation(enc._h, flags)
+        for _ in range(2):
+            enc.encode(3, False, False)
+        tot = 0.0
+        for _ in range(5):
+            enc.encode(3, False, False)
+            tot += enc.kernel_ms()["encode"]
+        print(f"kernel v{ver} ablate={flags:2d} {name:18s} {tot/5:.4f} ms", flush=True)
+    lib().yk_set_ablation(enc._h, 0)
     tot = 0.0
     for _ in range(5):
-        enc.encode(3, False, False)
+        enc.encode(3, True, False)
         tot += enc.kernel_ms()["encode"]
-    print(f"ablate={flags:2d} {name:22s} encode kernel {tot/5:.4f} ms", flush=True)
-lib().yk_set_ablation(enc._h, 0)
-for m3 in (False, True):
-    tot = 0.0
-    for _ in range(5):
-        enc.encode(3, m3, False)
-        tot += enc.kernel_ms()["encode"]
-    print(f"mode3={m3} encode kernel {tot/5:.4f} ms")
+    print(f"kernel v{ver} mode3BitOnly                    {tot/5:.4f} ms", flush=True)

@@ -74,6 +74,7 @@ SIGNATURES = {
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
+    "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),
     "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 

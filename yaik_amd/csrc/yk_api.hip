@@ -239,6 +239,11 @@ int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes) {
 }
 
 // ---- fused encode ------------------------------------------------------------------------------------
+int yk_set_kernel_version(yk_ctx* c, int version) {
+    if (!c || (version != 1 && version != 2)) return YK_ERR_BAD_ARG;
+    c->kernelVersion = version; return YK_OK;
+}
+
 int yk_set_ablation(yk_ctx* c, int flags) { if (!c) return YK_ERR_BAD_ARG; c->ablate = flags; return YK_OK; }
 
 int yk_set_dst_fill(yk_ctx* c, int32_t fill) { if (!c) return YK_ERR_BAD_ARG; c->dstFill = fill; return YK_OK; }

@@ -83,6 +83,7 @@ struct yk_ctx {
     hipEvent_t ev[6] = {};
     float msEncode = 0, msAlpha = 0, msPack = 0;
     int ablate = 0;
+    int kernelVersion = 2;              // 1 = yk_encode_kernel (lane = pixel row), 2 = yk_encode2_kernel (lane = 4x4 cell)
 };
 
 int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
@@ -94,3 +95,4 @@ int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
 int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
 int yk_launch_pack(yk_ctx* c);
 int yk_launch_corners(yk_ctx* c);
+int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P);

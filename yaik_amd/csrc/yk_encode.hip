@@ -609,6 +609,7 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst)
     for (int i = 0; i < 3; i++) P.dst[i] = c->dst[i];
     P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
     P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
+    if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
     dim3 grid(P.xBB64, P.yBB64);
     hipLaunchKernelGGL(yk_encode_kernel, grid, dim3(256), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());

@@ -1,0 +1,494 @@
+// yk_encode2.hip — second-generation fused kernel (same results as yk_encode_kernel, different work decomposition).
+//
+//   a6       7x EncoderContext::FittingQuadSmooth            (encoder/EncoderContext.cpp:3710-4363)
+//   a10-a13  DynamicTileEncode / GetMinMax_Y / GetTileDynamic_Y / DynamicTile::buildTable
+//                                                             (encoder/EncoderContext.cpp:625-1212, 4365-4602; Plane.cpp:489)
+//
+// Work decomposition: one workgroup (4 wave64) per 64x64 block as before, but a LANE owns a whole 4x4 CELL (16 pixels) and a
+// wave covers four 16x16 macro-tiles at once (lane = macroTile*16 + cellY*4 + cellX).  Consequences:
+//   * the per-tile work of a gradient pass (corner fetch, Round6/Round6P, row blends) is amortised over 16 pixels per lane;
+//   * a 4x4 tile is one lane, an 8x8 tile four lanes: tile-level reductions are ballots against a lane mask or two shuffles;
+//   * every pass first tests ONE row of every cell; if that already rejects every viable tile of the wave (noise, mild noise)
+//     the other three rows are never evaluated;
+//   * the mode-selection sums of the range quantiser are summed in tree order and accepted only when a rigorous rounding
+//     margin separates the modes; ambiguous tiles (rare) are re-summed in the reference's exact sequential order.
+#include "yk_common.h"
+#include "yk_curves.h"
+#include "yk_device.h"
+
+__constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
+
+#define LS YK_LSTRIDE
+
+__device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
+__device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
+__device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
+
+// One gradient pass for the four macro-tiles of a wave.  Arithmetic identical to yk_grad_pass (see yk_encode.hip): with
+// 1/16-unit weights S' = (TL*lx+TR*rx)*wy + (BL*lx+BR*rx)*wb fits 16 bits and the six variants of EncoderContext.cpp:3929-3991
+// are range tests on D = S' - 256*cur per corner set.
+template <int SX, int SY>
+__device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lcell, const int cx, const int cy, const int lane,
+                                             const uint32_t (&pw)[16], unsigned long long& cov, const unsigned long long deadLanes,
+                                             const int gxCell, const int gyCell, const int w, const int h, const int rf,
+                                             uint32_t* s_bm, const int bxCell, const int byCell) {
+    constexpr int TX = 1 << SX, TY = 1 << SY, NX = TX / 4, NY = TY / 4;
+    const int dcx = cx & (NX - 1), dcy = cy & (NY - 1);                  // this cell's offset inside its tile, in cells
+    const int olane = lane - (dcy * 4 + dcx);                            // lane that owns the tile's origin cell
+    constexpr unsigned long long rowPat = (1ULL << NX) - 1ULL;
+    constexpr unsigned long long P0 = rowPat | (NY >= 2 ? rowPat << 4 : 0ULL) | (NY == 4 ? (rowPat << 8) | (rowPat << 12) : 0ULL);
+    const unsigned long long tm = P0 << olane;                           // lanes (= cells) of this lane's tile
+    const int tgx = gxCell - dcx * 4, tgy = gyCell - dcy * 4;            // tile origin, stripe-local pixels
+    const bool inside = (tgx + TX <= w) && (tgy + TY <= h);
+    const bool allow = inside && (((cov >> olane) & 1ULL) == 0ULL);      // top-left pixel of the tile uncovered (:3871-3875)
+    bool viable = allow && ((deadLanes & tm) == 0ULL);
+    if (__ballot(viable) == 0ULL) return;
+
+    const int lo = lcell - (dcy * 4) * LS - dcx * 4;                     // LDS word of the tile origin
+    const uint32_t cw[4] = { s_pix[lo], s_pix[lo + TX], s_pix[lo + TY * LS], s_pix[lo + TY * LS + TX] };   // TL, TR, BL, BR
+    int cr[3][3][4];                                                     // [set][channel][corner]
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int v = y2_byte(cw[k], ch);
+            cr[0][ch][k] = v; cr[1][ch][k] = y2_round6(v); cr[2][ch][k] = y2_round6p(v);
+        }
+    const int lx0 = 16 - ((dcx * 4) << (4 - SX));                        // weight of the cell's first pixel column
+    const int loO = -256 * rf, hiO = 256 * rf + 255, loR = loO - 127, hiR = hiO - 127;
+    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int wy = 16 - ((dcy * 4 + r) << (4 - SY)), wb = 16 - wy;
+        int cc[12];                                                      // 256 * current pixel, this row only (bounds live registers)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cc[i * 3 + 0] = (int)((pw[r * 4 + i] << 8) & 0xFF00u);
+            cc[i * 3 + 1] = (int)(pw[r * 4 + i] & 0xFF00u);
+            cc[i * 3 + 2] = (int)((pw[r * 4 + i] >> 8) & 0xFF00u);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int L = cr[s][ch][0] * wy + cr[s][ch][2] * wb, R = cr[s][ch][1] * wy + cr[s][ch][3] * wb;
+                const int dL = L - R;
+                int S = (R << 4) + dL * lx0;                             // S' of the first pixel of the row
+                const int step = dL << (4 - SX);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int D = S - cc[i * 3 + ch];
+                    mn[s] = min(mn[s], D); mx[s] = max(mx[s], D);
+                    S -= step;
+                }
+            }
+        }
+        if (r == 0) {
+            // after one row: a tile is already lost if each of its six variants has a failing lane; if that holds for every
+            // viable tile of the wave the remaining three rows cannot change any decision.
+            bool lost = true;
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const unsigned long long bO = __ballot((mn[s] < loO) | (mx[s] > hiO)), bR = __ballot((mn[s] < loR) | (mx[s] > hiR));
+                lost = lost && ((bO & tm) != 0ULL) && ((bR & tm) != 0ULL);
+            }
+            viable = viable && !lost;
+            if (__ballot(viable) == 0ULL) return;
+        }
+    }
+    bool anyPass = false;                                                // :3998
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const unsigned long long bO = __ballot((mn[s] < loO) | (mx[s] > hiO)), bR = __ballot((mn[s] < loR) | (mx[s] > hiR));
+        anyPass = anyPass || ((bO & tm) == 0ULL) || ((bR & tm) == 0ULL);
+    }
+    const bool accept = viable && anyPass;
+    cov |= __ballot(accept);                                             // paint coverage (:4029-4037): bit = lane = cell
+    if (accept && dcx == 0 && dcy == 0) {                                // the origin cell's lane sets the bitmap bit (:4026)
+        const int tbx = bxCell >> SX, tby = byCell >> SY;                // tile coordinates inside the 64x64 block
+        int bit;
+        if (SX == 4 && SY == 4) bit = 0 + tby * 4 + tbx;
+        else if (SX == 4 && SY == 3) bit = 32 + tby * 4 + tbx;
+        else if (SX == 3 && SY == 4) bit = 64 + tby * 8 + tbx;
+        else if (SX == 3 && SY == 3) bit = 96 + tby * 8 + tbx;
+        else if (SX == 3 && SY == 2) bit = 160 + (tby >> 3) * 64 + (tby & 7) * 8 + tbx;
+        else if (SX == 2 && SY == 3) bit = 288 + (tbx >> 3) * 64 + tby * 8 + (tbx & 7);
+        else bit = 416 + ((tby >> 3) * 2 + (tbx >> 3)) * 64 + (tby & 7) * 8 + (tbx & 7);
+        atomicOr(&s_bm[bit >> 5], 1u << (bit & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pix[YK_LROWS * LS];
+    __shared__ uint32_t s_bm[24];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][16][80];      // per wave, per 8x8 tile: 3x16 + 3x8 entries of (LUT << 4)
+    __shared__ __attribute__((aligned(16))) float s_curve[6][16];
+    __shared__ __attribute__((aligned(16))) float s_chain[4][6][68];        // exact-order fallback, one tile-plane at a time per wave
+    __shared__ float s_err[4][8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int BX = blockIdx.x, BY = blockIdx.y;
+    const int w = P.w, h = P.h;
+
+    if (tid < 24) s_bm[tid] = 0;
+    if (tid < 96) s_curve[tid >> 4][tid & 15] = c_curve2[tid >> 4][tid & 15];
+    // ---- stage the clamped 65x65 block (Plane::GetPixelValue clamp, encoder/framework.h:116-121); all loads first ------
+    {
+        const int g4 = (tid & 15) * 4, r0 = tid >> 4;
+        const int gx = BX * 64 + g4;
+        const bool inX = gx + 3 < w;
+        int4 R[4], G[4], B[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int gy = min(BY * 64 + r0 + 16 * k, P.hAvail - 1);
+            if (inX) {
+                const size_t off = (size_t)gy * P.strideElems + gx;
+                R[k] = *reinterpret_cast<const int4*>(P.plane[0] + off);
+                G[k] = *reinterpret_cast<const int4*>(P.plane[1] + off);
+                B[k] = *reinterpret_cast<const int4*>(P.plane[2] + off);
+            } else {
+                const size_t off = (size_t)gy * P.strideElems + (w - 1);
+                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                R[k] = make_int4(r, r, r, r); G[k] = make_int4(gg, gg, gg, gg); B[k] = make_int4(b, b, b, b);
+            }
+        }
+        int4 Rb = make_int4(0, 0, 0, 0), Gb = Rb, Bb = Rb;
+        if (tid < 16) {
+            const int gy = min(BY * 64 + 64, P.hAvail - 1);
+            if (inX) {
+                const size_t off = (size_t)gy * P.strideElems + gx;
+                Rb = *reinterpret_cast<const int4*>(P.plane[0] + off);
+                Gb = *reinterpret_cast<const int4*>(P.plane[1] + off);
+                Bb = *reinterpret_cast<const int4*>(P.plane[2] + off);
+            } else {
+                const size_t off = (size_t)gy * P.strideElems + (w - 1);
+                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                Rb = make_int4(r, r, r, r); Gb = make_int4(gg, gg, gg, gg); Bb = make_int4(b, b, b, b);
+            }
+        }
+        uint32_t hcol = 0;
+        const int hr = tid - 64;
+        if (hr >= 0 && hr < YK_LROWS) {
+            const int gy = min(BY * 64 + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
+            const size_t off = (size_t)gy * P.strideElems + gxh;
+            hcol = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 o = make_uint4((uint32_t)R[k].x | ((uint32_t)G[k].x << 8) | ((uint32_t)B[k].x << 16),
+                                       (uint32_t)R[k].y | ((uint32_t)G[k].y << 8) | ((uint32_t)B[k].y << 16),
+                                       (uint32_t)R[k].z | ((uint32_t)G[k].z << 8) | ((uint32_t)B[k].z << 16),
+                                       (uint32_t)R[k].w | ((uint32_t)G[k].w << 8) | ((uint32_t)B[k].w << 16));
+            *reinterpret_cast<uint4*>(&s_pix[(r0 + 16 * k) * LS + g4]) = o;
+        }
+        if (tid < 16) {
+            const uint4 o = make_uint4((uint32_t)Rb.x | ((uint32_t)Gb.x << 8) | ((uint32_t)Bb.x << 16),
+                                       (uint32_t)Rb.y | ((uint32_t)Gb.y << 8) | ((uint32_t)Bb.y << 16),
+                                       (uint32_t)Rb.z | ((uint32_t)Gb.z << 8) | ((uint32_t)Bb.z << 16),
+                                       (uint32_t)Rb.w | ((uint32_t)Gb.w << 8) | ((uint32_t)Bb.w << 16));
+            *reinterpret_cast<uint4*>(&s_pix[64 * LS + g4]) = o;
+        }
+        if (hr >= 0 && hr < YK_LROWS) s_pix[hr * LS + 64] = hcol;
+    }
+    __syncthreads();
+
+    // ---- lane geometry: wave = macro-tile row `wave` of the block, lane = macroTile(q)*16 + cellY*4 + cellX ------------
+    const int q = lane >> 4, cell = lane & 15, cx = cell & 3, cy = cell >> 2;
+    const int bxCell = q * 16 + cx * 4, byCell = wave * 16 + cy * 4;          // cell origin inside the block
+    const int gxCell = BX * 64 + bxCell, gyCell = BY * 64 + byCell;          // stripe-local pixels
+    const int lcell = byCell * LS + bxCell;
+    const bool mtIn = (BX * 64 + q * 16 < w) && (BY * 64 + wave * 16 < h);    // macro-tile origin inside the image
+
+    uint32_t pw[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint4 t = *reinterpret_cast<const uint4*>(&s_pix[lcell + r * LS]);
+        pw[r * 4 + 0] = t.x; pw[r * 4 + 1] = t.y; pw[r * 4 + 2] = t.z; pw[r * 4 + 3] = t.w;
+    }
+
+    // ---- a6: seven passes --------------------------------------------------------------------------------------
+    unsigned long long cov = 0ULL;                                           // bit = lane = 4x4 cell covered
+    {
+        // S' is linear in x inside any tile, so |c(x-1)-2c(x)+c(x+1)| <= 4*rejectFactor+1 is necessary for acceptance of every
+        // tile containing the three pixels (see yk_encode.hip); rows 0 and 2 of the cell are tested.
+        bool dead = !mtIn;
+        {
+            const int lim = 4 * P.rejectFactor + 1;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const int c0 = y2_byte(pw[r * 4], ch), c1 = y2_byte(pw[r * 4 + 1], ch), c2 = y2_byte(pw[r * 4 + 2], ch), c3 = y2_byte(pw[r * 4 + 3], ch);
+                    dead |= (abs(c0 - 2 * c1 + c2) > lim) | (abs(c1 - 2 * c2 + c3) > lim);
+                }
+        }
+        const unsigned long long deadLanes = __ballot(dead);
+        if (~deadLanes != 0ULL && !(P.ablate & 2)) {
+            y2_grad_pass<4, 4>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+            if (~(cov | deadLanes) != 0ULL) {
+                y2_grad_pass<4, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 4>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 2>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 2>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+            }
+        }
+    }
+    const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
+    if (cell == 0 && mtIn) P.coverage[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
+
+    // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
+    int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
+    if (P.bounds) {
+        const int b0 = P.bounds[0], b1 = P.bounds[1], b2 = P.bounds[2], b3 = P.bounds[3];
+        discard = P.bounds[4];
+        cxB = (b0 >> 3) << 3; cyB = (b1 >> 3) << 3;
+        cw = (((b2 + 7) >> 3) << 3) - cxB; chh = (((b3 + 7) >> 3) << 3) - cyB;
+    }
+    const int cxl = cx & 1, cyl = cy & 1;
+    const int tgx = gxCell - cxl * 4, tgyl = gyCell - cyl * 4, tgy = tgyl + P.y0;   // tile origin (stripe-local / full-image row)
+    const bool tileIn = (tgx + 8 <= w) && (tgyl + 8 <= h);
+    // LeftRightOrder over the constraint box incl. its zero-size rule (encoder/framework.h:239-255)
+    const bool part = tileIn && tgx >= cxB && tgx < cxB + cw && tgy >= cyB && tgy < cyB + chh && (tgx + 8 <= cw) && (tgy + 8 <= chh);
+    const bool keepMT = (P.keep == nullptr) || discard || (mtIn && P.keep[mtIdx] != 0);
+    const bool tileLive = part && keepMT;
+    const int l00 = lane - cyl * 4 - cxl;                                    // lane of the tile's top-left cell
+    const bool v00 = !((cov >> l00) & 1ULL), v10 = !((cov >> (l00 + 1)) & 1ULL), v01 = !((cov >> (l00 + 4)) & 1ULL), v11 = !((cov >> (l00 + 5)) & 1ULL);
+    const bool valid = tileLive && !((cov >> lane) & 1ULL);                  // valid = mipmapMask && !smoothMap (Plane.cpp:527)
+    const int nTop = (int)v00 + (int)v10, nBot = (int)v01 + (int)v11;
+    const int valueCount = tileLive ? 16 * (nTop + nBot) : 0;
+    const int tileIdx = (tgyl >> 3) * P.tilesW + (tgx >> 3);
+    const size_t T8 = (size_t)P.tilesW * P.tilesH;
+    const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the wave (0..15)
+    const bool writer = (cxl == 0) && (cyl == 0) && tileIn;                  // one lane per tile writes count / def
+
+    if (__ballot(valid) == 0ULL || (P.ablate & 1)) {
+        if (writer) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
+        }
+    } else {
+        uint16_t* lut = &s_lut[wave][tw][0];
+        const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
+        for (int p = 0; p < 3; p++) {
+            // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
+            int mn = 99999999, mx = -99999999;
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const int v = y2_byte(pw[k], p); mn = min(mn, v); mx = max(mx, v); }
+            }
+            mn = min(mn, __shfl_xor(mn, 1)); mx = max(mx, __shfl_xor(mx, 1));
+            mn = min(mn, __shfl_xor(mn, 4)); mx = max(mx, __shfl_xor(mx, 4));
+            if (mn == 99999999) { mn = 0; mx = 0; }
+            // DynamicTile::buildTable (:625-699)
+            const int min_ = min(mn, 224);
+            int diff = mx - min_; if (diff < 16) diff = 16;
+            const int base = (min_ * 63 + 112) / 224;
+            const int BN = (base * 224) / 63;
+            const int d8 = max(diff, 32);
+            const int scale = 223 - BN;
+            const int dnum = (d8 - 32) * 127 + (scale - 1);                  // see yk_encode.hip / yk_selftest 1
+            const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
+            const int rangeDecode = (dist * scale) / 127 + 32;
+            const float Rf = (float)rangeDecode, BNf = (float)BN;
+            // the four lanes of the tile build the 72 LUT entries: lane j4 takes entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit)
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    lut[m * 16 + j4 * 4 + k] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 4 + k], Rf))) << 4);
+#pragma unroll
+            for (int m = 3; m < 6; m++)
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    lut[48 + (m - 3) * 8 + j4 * 2 + k] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf))) << 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // v<<4 per pixel and a FAST reciprocal (v_rcp_f32, <= 1 ulp): the screening sums below only need ~1e-7 relative
+            // accuracy per term; the exact terms (IEEE division) are recomputed in the rare fallback.
+            uint32_t vs[16]; float rv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int v = y2_byte(pw[k], p);
+                vs[k] = (uint32_t)v << 4;
+                rv[k] = (valid && v != 0) ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // r = 0 -> the term is exactly +0 (skipped pixel)
+            }
+            // The reference adds the 64 exact terms minDiff/v SEQUENTIALLY in float (:885) and, walking the modes in order, keeps
+            // mode m when err_m <= best (:897).  Any summation order of n <= 64 non-negative floats is within gamma_63 = 3.76e-6
+            // (relative) of the exact sum and md*rcp(v) is within 2.5e-7 of the correctly rounded quotient, so a screening sum T
+            // (tree order, fast reciprocal) differs from the reference's sum by < 8e-6 relative.  Each of the reference's
+            // comparisons is therefore decided with certainty when the two sums are separated by 2e-5, or tie exactly with
+            // identical per-pixel minDiffs (then the reference's sums are identical too: the later mode wins), or are both
+            // exactly 0 (all terms 0).  Any other case (rare) flags the tile for exact re-summation in the reference's order.
+            // minDiff fits a byte: a LUT entry of 256 needs min >= 223, hence |256 - v| <= 33.
+            int bestMode = -1; float bestT = 0.0f;
+            uint32_t cLo = 0, cHi = 0, bMd[4] = { 0, 0, 0, 0 };
+            bool amb = false;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                if (m >= P.startMode && !(P.ablate & 4)) {
+                    const int cnt = m < 3 ? 16 : 8;
+                    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8));
+                    uint32_t e[16];
+#pragma unroll
+                    for (int k = 0; k < cnt / 2; k++) { const uint32_t wv = lw[k]; e[2 * k] = wv & 0xFFFFu; e[2 * k + 1] = wv >> 16; }
+                    float s = 0.0f;
+                    uint32_t mLo = 0, mHi = 0, mMd[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int n = 0; n < cnt; n++) key = min(key, __usad(e[n], vs[k], n));          // first nearest entry (:873-881)
+                        const uint32_t md = key >> 4;
+                        if (k < 8) mLo |= (key & 15u) << (4 * k); else mHi |= (key & 15u) << (4 * (k - 8));
+                        mMd[k >> 2] |= md << (8 * (k & 3));
+                        s = __fadd_rn(s, __fmul_rn((float)(int)md, rv[k]));
+                    }
+                    s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
+                    bool take;
+                    if (bestMode < 0) take = true;
+                    else if (__fmul_rn(s, 1.00002f) < bestT) take = true;                    // surely smaller
+                    else if (__fmul_rn(bestT, 1.00002f) < s) take = false;                   // surely larger
+                    else if (s == bestT) {
+                        if (s == 0.0f) take = true;                                          // both exactly zero
+                        else {
+                            const bool same = !valid || (mMd[0] == bMd[0] && mMd[1] == bMd[1] && mMd[2] == bMd[2] && mMd[3] == bMd[3]);
+                            const bool tileSame = (__ballot(!same) & (0x33ULL << l00)) == 0ULL;   // the tile's four lanes are active together
+                            take = true;
+                            if (!tileSame) amb = true;
+                        }
+                    } else { take = s <= bestT; amb = true; }
+                    if (take) { bestMode = m; bestT = s; cLo = mLo; cHi = mHi; bMd[0] = mMd[0]; bMd[1] = mMd[1]; bMd[2] = mMd[2]; bMd[3] = mMd[3]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // keep the modes sequential: bounds the live registers
+            }
+            if (bestMode < 0) bestMode = 5;                                  // only reachable with the timing-only ablation flag 4
+            if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
+            unsigned long long ambMask = __ballot(amb && tileLive);
+            while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
+                const int al = __ffsll((long long)ambMask) - 1;              // a lane of the tile
+                const int ac = al & 15;
+                const int a00 = al - ((ac >> 2) & 1) * 4 - (ac & 1);        // top-left lane of that tile
+                ambMask &= ~(0x33ULL << a00);
+                if (l00 == a00) {                                            // the four lanes of the tile publish their exact terms in pixel order
+                    for (int m = P.startMode; m < 6; m++) {
+                        const uint16_t* lm = lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8);
+                        const int cnt = m < 3 ? 16 : 8;
+                        for (int r = 0; r < 4; r++) {
+                            float qv[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int k = r * 4 + i;
+                                uint32_t v4 = 0;
+#pragma unroll
+                                for (int kk = 0; kk < 16; kk++) v4 = (kk == k) ? vs[kk] : v4;
+                                uint32_t key = 0xFFFFFFFFu;
+                                for (int n = 0; n < cnt; n++) key = min(key, __usad((uint32_t)lm[n], v4, (uint32_t)n));
+                                const int v = (int)(v4 >> 4);
+                                qv[i] = (valid && v != 0) ? __fdiv_rn((float)(int)(key >> 4), (float)v) : 0.0f;      // divss (:885)
+                            }
+                            *reinterpret_cast<float4*>(&s_chain[wave][m][(cyl * 4 + r) * 8 + cxl * 4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 6 && lane >= P.startMode) {                       // errorDist += minDiff / v in row-major pixel order (:885)
+                    float s = 0.0f;
+                    const float4* cp = reinterpret_cast<const float4*>(&s_chain[wave][lane][0]);
+                    for (int k = 0; k < 16; k++) {
+                        const float4 a = cp[k];
+                        s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, a.x), a.y), a.z), a.w);
+                    }
+                    s_err[wave][lane] = s;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (l00 == a00) {                                            // last mode whose error is <= the best so far (:897-905)
+                    bestMode = -1; float bestErr = 99999999.0f;
+                    for (int m = P.startMode; m < 6; m++) {
+                        const float e = s_err[wave][m];
+                        if (e <= bestErr) { bestErr = e; bestMode = m; }
+                    }
+                    const uint16_t* lm = lut + (bestMode < 3 ? bestMode * 16 : 48 + (bestMode - 3) * 8);
+                    const int cnt = bestMode < 3 ? 16 : 8;
+                    cLo = 0; cHi = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        uint32_t key = 0xFFFFFFFFu;
+                        for (int n = 0; n < cnt; n++) key = min(key, __usad((uint32_t)lm[n], vs[k], (uint32_t)n));
+                        if (k < 8) cLo |= (key & 15u) << (4 * k); else cHi |= (key & 15u) << (4 * (k - 8));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // codes of the best mode, nibble-packed at the position of the lane's pixels among the tile's valid pixels (:1174-1190)
+            if (valid) {
+                uint8_t* slot = P.slots + ((size_t)p * T8 + tileIdx) * YK_SLOT;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int yIn = cyl * 4 + r;
+                    const int pos = (yIn < 4) ? (yIn * 4 * nTop + (cxl ? 4 * (int)v00 : 0))
+                                              : (16 * nTop + (yIn - 4) * 4 * nBot + (cxl ? 4 * (int)v01 : 0));
+                    const uint32_t code16 = ((r < 2 ? cLo : cHi) >> (16 * (r & 1))) & 0xFFFFu;
+                    *reinterpret_cast<uint16_t*>(slot + (pos >> 1)) = (uint16_t)code16;
+                    if (P.wantDst) {
+                        const uint16_t* lb = lut + (bestMode < 3 ? bestMode * 16 : 48 + (bestMode - 3) * 8);
+                        int32_t* drow = P.dst[p] + (size_t)(gyCell + r) * w + gxCell;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) drow[i] = (int32_t)(lb[(code16 >> (4 * i)) & 15u] >> 4);
+                    }
+                }
+            }
+            if (writer) {
+                P.tileCount[p * T8 + tileIdx] = (uint8_t)valueCount;
+                // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
+                P.tileDef[p * T8 + tileIdx] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (((uint32_t)dist & 255u) << 7) | ((uint32_t)base & 255u));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- block bitmaps -> the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805) -----------
+    __syncthreads();
+    if (tid == 0) {
+        const int i64 = BY * P.xBB64 + BX;
+        reinterpret_cast<uint16_t*>(P.bitmap[0])[i64] = (uint16_t)s_bm[0];
+        reinterpret_cast<uint32_t*>(P.bitmap[1])[i64] = s_bm[1];
+        reinterpret_cast<uint32_t*>(P.bitmap[2])[i64] = s_bm[2];
+        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2] = s_bm[3];
+        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2 + 1] = s_bm[4];
+        for (int s = 0; s < 2; s++) {
+            if (BY * 2 + s < P.yBB32) {
+                const int i = (BY * 2 + s) * P.xBB64 + BX;
+                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2] = s_bm[5 + s * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2 + 1] = s_bm[6 + s * 2];
+            }
+            if (BX * 2 + s < P.xBB32) {
+                const int i = BY * P.xBB32 + BX * 2 + s;
+                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2] = s_bm[9 + s * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2 + 1] = s_bm[10 + s * 2];
+            }
+        }
+        for (int sy = 0; sy < 2; sy++) for (int sx = 0; sx < 2; sx++) {
+            if (BY * 2 + sy < P.yBB32 && BX * 2 + sx < P.xBB32) {
+                const int i = (BY * 2 + sy) * P.xBB32 + BX * 2 + sx;
+                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2] = s_bm[13 + (sy * 2 + sx) * 2];
+                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2 + 1] = s_bm[14 + (sy * 2 + sx) * 2];
+            }
+        }
+    }
+}
+
+int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
+    dim3 grid(P.xBB64, P.yBB64);
+    hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(256), 0, c->stream, P);
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
