@@ -52,17 +52,26 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a HIP device (no CPU fallback on the product path)", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switch (1-GPU box / CI): YK_BENCH_BACKEND=gloo runs every rank on GPU 0 and moves the gather through host
+    # memory, so the whole N > 1 code path can be exercised without N GPUs.  The driver's real runs use nccl (= RCCL).
+    backend = os.environ.get("YK_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = torch.device("cpu") if rehearsal else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W = args.size
     planes = synth_planes_torch(W, n_planes=4, seed=12345 + rank, device=dev)      # frame f uses seed 12345+f
     torch.cuda.synchronize()
 
-    enc = HipTileEncoder(local_rank)
+    enc = HipTileEncoder(dev_index)
     enc.set_image(planes)
     blob = torch.empty(enc.export_capacity(), dtype=torch.uint8, device=dev) if world > 1 else None
 
@@ -72,7 +81,8 @@ def main() -> int:
         enc.encode(3, args.mode3, False)
         if world > 1:
             sizes = enc.export_tile_maps(blob)
-            ykd.gather_tile_maps(blob, int(sizes[14]), sizes, dist, dst=0)
+            payload = blob[: int(sizes[14])].cpu() if rehearsal else blob
+            ykd.gather_tile_maps(payload, int(sizes[14]), sizes, dist, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -95,7 +105,7 @@ def main() -> int:
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     for n in kms:
