@@ -19,51 +19,65 @@
 __constant__ float c_curve[6][16] = YK_CURVE_TABLE;
 
 // ------------------------------------------------------------------------------------------------------------------
-// a9: alpha tile-reject, stage 1.  One workgroup per 64x64 block, wave w owns macro-tile row w of the block.
-// keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed form of quadRecursion with
-// maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (:416-422).
+// a9: alpha tile-reject, stage 1.  keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed
+// form of quadRecursion with maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (:416-422).
+//
+// The plane is streamed in memory order like a reduction: a work unit is (row, 4096-pixel segment), every lane has four
+// 16-byte loads in flight and a wave instruction covers 1 KB of one row.  Four adjacent lanes hold the 16 pixels of one
+// tile row; a non-zero group raises the tile's flag with an idempotent byte store into the pre-zeroed map, so the
+// streaming path has no atomics.  The bounding box is derived from the flags afterwards (yk_alpha_bbox_kernel).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h, int y0,
-                                                       uint8_t* __restrict__ keep, int mtW, int mtH, int32_t* __restrict__ bbox /*x0,y0,x1,y1*/) {
-    // grid-stride over 64x64 blocks: a wave that only issues four 16-byte loads is too short-lived to keep HBM busy,
-    // so each wave walks many blocks and keeps its bounding box in registers until the end.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nbx = (w + 63) >> 6, nby = (h + 63) >> 6;
-    int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
-    for (int blk = blockIdx.x; blk < nbx * nby; blk += gridDim.x) {
-        const int bx = blk % nbx, by = blk / nbx;
-        const int mty = by * 4 + wave;
-        if (mty >= mtH) continue;
-        const int gx = bx * 64 + (lane & 15) * 4;
-        int nz = 0;
+__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h,
+                                                       uint8_t* __restrict__ keep, int mtW) {
+    const int lane = threadIdx.x & 63;
+    const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
+    const int nSeg = (vecPerRow + 1023) >> 10;
+    const int nUnits = nSeg * h;
+    for (int u = blockIdx.x; u < nUnits; u += gridDim.x) {
+        const int y = u / nSeg, seg = u - y * nSeg;
+        const int32_t* row = alpha + (size_t)y * strideElems;
+        int4 a[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int gy = mty * 16 + k * 4 + (lane >> 4);
-            if (gx < w && gy < h) {
-                const int4 a = *reinterpret_cast<const int4*>(alpha + (size_t)gy * strideElems + gx);
-                nz |= a.x | a.y | a.z | a.w;
-            }
+            const int xv = seg * 1024 + k * 256 + threadIdx.x;
+            a[k] = make_int4(0, 0, 0, 0);
+            if (xv < vecPerRow) a[k] = *reinterpret_cast<const int4*>(row + xv * 4);
         }
-        const unsigned long long b = __ballot(nz != 0);
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int mtx = bx * 4 + m;
-            if (mtx >= mtW) break;
-            const bool kept = (b & (0x000F000F000F000FULL << (4 * m))) != 0;
-            if (lane == 0) keep[mty * mtW + mtx] = kept ? 1 : 0;
-            if (kept) {
-                x0 = min(x0, mtx * 16); x1 = max(x1, mtx * 16 + 16);
-                gy0 = min(gy0, y0 + mty * 16); gy1 = max(gy1, y0 + mty * 16 + 16);
-            }
+        for (int k = 0; k < 4; k++) {
+            const int xv = seg * 1024 + k * 256 + threadIdx.x;
+            const unsigned long long b = __ballot((a[k].x | a[k].y | a[k].z | a[k].w) != 0);
+            if ((lane & 3) == 0 && ((b >> lane) & 0xFULL) != 0) keep[(size_t)(y >> 4) * mtW + (xv >> 2)] = 1;
         }
     }
-    if (lane == 0 && x1 >= 0) {
-        // min/max are monotone, so a (possibly stale) read that already beats our value makes the atomic unnecessary
-        // (a single address only sustains ~88 atomics/us).
-        if (__hip_atomic_load(&bbox[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > x0) atomicMin(&bbox[0], x0);
-        if (__hip_atomic_load(&bbox[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x1) atomicMax(&bbox[2], x1);
-        if (__hip_atomic_load(&bbox[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > gy0) atomicMin(&bbox[1], gy0);
-        if (__hip_atomic_load(&bbox[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gy1) atomicMax(&bbox[3], gy1);
+}
+
+// bounding box of the kept 16x16 tiles (quadRecursion's boundingL/T/R/B, EncoderContext.cpp:416-422) from the keep flags;
+// one guarded atomic per workgroup and bound (a single address only sustains ~88 atomics/us).
+__global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint8_t* __restrict__ keep, int mtW, int mtH, int y0, int32_t* __restrict__ bbox) {
+    __shared__ int s_red[4][4];
+    int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
+    const int n = mtW * mtH;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (keep[i]) {
+            const int my = i / mtW, mx = i - my * mtW;
+            x0 = min(x0, mx * 16); x1 = max(x1, mx * 16 + 16);
+            gy0 = min(gy0, y0 + my * 16); gy1 = max(gy1, y0 + my * 16 + 16);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        x0 = min(x0, __shfl_xor(x0, d)); x1 = max(x1, __shfl_xor(x1, d));
+        gy0 = min(gy0, __shfl_xor(gy0, d)); gy1 = max(gy1, __shfl_xor(gy1, d));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[wave][0] = x0; s_red[wave][1] = gy0; s_red[wave][2] = x1; s_red[wave][3] = gy1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            x0 = min(x0, s_red[k][0]); gy0 = min(gy0, s_red[k][1]); x1 = max(x1, s_red[k][2]); gy1 = max(gy1, s_red[k][3]);
+        }
+        if (x1 >= 0) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], gy0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], gy1); }
     }
 }
 
@@ -528,46 +542,73 @@ __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ b
     if (threadIdx.x == 0) { totals[p * 2] = baseD; totals[p * 2 + 1] = baseN; }
 }
 
-__global__ __launch_bounds__(256) void yk_zero_kernel(uint32_t* __restrict__ nib, size_t strideWords, const uint32_t* __restrict__ totals) {
+// Words of the nibble streams that two scan blocks share (and the tail word) are OR-ed into by yk_pack_kernel, so they are
+// cleared first; every other word of a stream is written whole.  One thread per scan block.
+__global__ __launch_bounds__(256) void yk_zero_kernel(uint32_t* __restrict__ nib, size_t strideWords, const uint32_t* __restrict__ blockSums, int nBlocks,
+                                                      const uint32_t* __restrict__ totals) {
     const int p = blockIdx.y;
-    const size_t words = ((size_t)totals[p * 2 + 1] + 7) / 8 + 1;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t* o = nib + (size_t)p * strideWords;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) o[i] = 0;
+    if (b < nBlocks) {
+        const uint32_t w = blockSums[((size_t)p * nBlocks + b) * 2] >> 3;
+        o[w] = 0;
+        if (w) o[w - 1] = 0;
+    }
+    if (b == 0) { const uint32_t w = totals[p * 2 + 1] >> 3; o[w] = 0; o[w + 1] = 0; if (w) o[w - 1] = 0; }
 }
 
+// One workgroup packs the nibbles of 1024 consecutive tiles: the per-tile slots are read as whole 16-byte vectors, shifted
+// into place in an LDS image of the block's piece of the stream, and that piece goes out as one contiguous run of words.
 __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
                                                        const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
                                                        uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords) {
     __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_out[YK_SCAN_TILE * 8 + 8];
     const int p = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
     const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
-    uint32_t tot;
-    const uint32_t en = yk_block_exscan(c, s_tmp, &tot);
-    const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &tot);
-    if (!c) return;
+    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (c) {
+        const uint4* sl = reinterpret_cast<const uint4*>(slots + ((size_t)p * T8 + i) * YK_SLOT);
+        const uint4 lo = sl[0];
+        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+        if (c > 32) { const uint4 hi = sl[1]; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w; }
+    }
+    uint32_t totN, totD;
+    const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
+    const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
+    if (totN == 0) return;                                                    // uniform over the workgroup
     const uint32_t baseN = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2], baseD = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2 + 1];
-    defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
-    // copy c nibbles from the tile slot to nibble offset o of the plane's stream (low nibble first)
-    const uint32_t o = baseN + en;
-    const uint32_t* sl = reinterpret_cast<const uint32_t*>(slots + ((size_t)p * T8 + i) * YK_SLOT);
-    uint32_t* out = nibOut + (size_t)p * nibStrideWords;
-    const uint32_t sh = (o & 7u) * 4u;
-    const uint32_t firstW = o >> 3, lastW = (o + c - 1) >> 3;
-    uint32_t carry = 0;
-    const uint32_t nW = (c + 7) >> 3;
-    for (uint32_t k = 0; k <= nW; k++) {
-        uint32_t wv = 0;
-        if (k < nW) {
-            wv = sl[k];
-            const uint32_t rem = c - k * 8;                       // nibbles of this word that are real
-            if (rem < 8) wv &= (1u << (rem * 4)) - 1u;
+    const uint32_t sh0 = baseN & 7u;
+    const uint32_t nWords = (sh0 + totN + 7) >> 3;
+    for (uint32_t k = threadIdx.x; k < nWords; k += YK_SCAN_TILE) s_out[k] = 0;
+    __syncthreads();
+    if (c) {
+        defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
+        // c nibbles of the slot (low nibble first) go to nibble offset o of the LDS image
+        const uint32_t o = sh0 + en;
+        const uint32_t sh = (o & 7u) * 4u;
+        const uint32_t firstW = o >> 3, lastW = (o + c - 1) >> 3;
+        uint32_t prev = 0;
+#pragma unroll
+        for (uint32_t k = 0; k <= 8; k++) {
+            uint32_t cur = 0;
+            if (k < 8 && k * 8 < c) {
+                cur = w[k];
+                const uint32_t rem = c - k * 8;                   // nibbles of this word that are real
+                if (rem < 8) cur &= (1u << (rem * 4)) - 1u;
+            }
+            const uint32_t outw = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32u - sh));
+            prev = cur;
+            const uint32_t wi = firstW + k;
+            if (wi <= lastW) { if (wi == firstW || wi == lastW) atomicOr(&s_out[wi], outw); else s_out[wi] = outw; }
         }
-        const uint32_t outw = sh ? ((wv << sh) | carry) : wv;
-        carry = sh ? (wv >> (32 - sh)) : 0;
-        const uint32_t wi = firstW + k;
-        if (wi > lastW) break;
-        if (wi == firstW || wi == lastW) atomicOr(&out[wi], outw); else out[wi] = outw;
+    }
+    __syncthreads();
+    uint32_t* out = nibOut + (size_t)p * nibStrideWords + (baseN >> 3);
+    for (uint32_t k = threadIdx.x; k < nWords; k += YK_SCAN_TILE) {
+        const uint32_t v = s_out[k];
+        if (k == 0 || k == nWords - 1) { if (v) atomicOr(&out[k], v); } else out[k] = v;
     }
 }
 
@@ -577,10 +618,13 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
 int yk_launch_alpha(yk_ctx* c) {
     static const int32_t init[16] = { 0, 0, 0, 0, 1, 0, 0, 0, 9999999, 9999999, -1, -1, 0, 0, 0, 0 };
     YK_HIP(c, hipMemcpyAsync(c->bounds, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    const int nBlocks = ((c->fullW + 63) / 64) * ((c->h + 63) / 64);
-    dim3 grid(nBlocks < 2048 ? nBlocks : 2048);
-    hipLaunchKernelGGL(yk_alpha_kernel, grid, dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h, c->y0,
-                       c->keep, c->mtW, c->mtH, c->bounds + 8);
+    YK_HIP(c, hipMemsetAsync(c->keep, 0, (size_t)c->mtW * c->mtH, c->stream));
+    const int nUnits = ((c->fullW / 4 + 1023) / 1024) * c->h;
+    hipLaunchKernelGGL(yk_alpha_kernel, dim3(nUnits < 4096 ? nUnits : 4096), dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h,
+                       c->keep, c->mtW);
+    YK_HIP(c, hipGetLastError());
+    const int nb = (c->mtW * c->mtH + 4095) / 4096;
+    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, c->stream, c->keep, c->mtW, c->mtH, c->y0, c->bounds + 8);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
@@ -621,7 +665,8 @@ int yk_launch_pack(yk_ctx* c) {
     const int nb = c->nScanBlocks;
     hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockSums, nb);
     hipLaunchKernelGGL(yk_scan2_kernel, dim3(3), dim3(1024), 0, c->stream, c->blockSums, nb, c->totals);
-    hipLaunchKernelGGL(yk_zero_kernel, dim3(512, 3), dim3(256), 0, c->stream, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4, c->totals);
+    hipLaunchKernelGGL(yk_zero_kernel, dim3((nb + 255) / 256, 3), dim3(256), 0, c->stream, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4,
+                       c->blockSums, nb, c->totals);
     hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, c->tileDef, c->slots, T8, c->blockSums, nb,
                        c->defsOut, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
     YK_HIP(c, hipGetLastError());
