@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline object is checked against (run on the GPU box via gpurun):
+#   pass 1  --kernel-trace --stats            -> per-kernel average duration
+#   pass 2+ --pmc ... (own runs, no tracing)  -> SQ counters, FETCH_SIZE, WRITE_SIZE (separate passes, see MI355X_MICROARCH.md)
+# usage: tools/profile_round.sh <tag>     (outputs under gpurun_out/prof_<tag>/ and the summary gpurun_out/prof_<tag>_summary.json)
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+ARGS="--steps 10 --warmup 2 --no-cpu --no-parity"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT.bench.json 2> $OUT.stats.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-parity > /dev/null 2> $OUT.pmc1.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-parity > /dev/null 2> $OUT.pmc2.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-parity > /dev/null 2> $OUT.pmc3.err
+python3 tools/summarize_prof.py $OUT > ${OUT}_summary.json
+cat ${OUT}_summary.json

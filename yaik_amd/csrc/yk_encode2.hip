@@ -21,6 +21,8 @@ __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 #define LS YK_LSTRIDE
 
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
+// |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
+__device__ __forceinline__ uint32_t y2_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
@@ -119,16 +121,30 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lc
     }
 }
 
+#define YK2_RUN 16
+#define YK2_LUTW 84
+
 __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pix[YK_LROWS * LS];
     __shared__ uint32_t s_bm[24];
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][16][80];      // per wave, per 8x8 tile: 3x16 + 3x8 entries of (LUT << 4)
+    // per wave, per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19); 3-bit mode m at
+    // [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint in the same units).
+    __shared__ __attribute__((aligned(16))) uint32_t s_lut[4][16][YK2_LUTW];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
     __shared__ __attribute__((aligned(16))) float s_chain[4][6][68];        // exact-order fallback, one tile-plane at a time per wave
     __shared__ float s_err[4][8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int BX = blockIdx.x, BY = blockIdx.y;
+    // XCD-aware block order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Blocks are
+    // taken in row-major runs of YK2_RUN; XCD k gets the k-th run of every group of 8 runs, so the halo column of a block is a
+    // line its right-hand neighbour streams through the same L2 at about the same time instead of a second fabric fetch,
+    // while every XCD still samples the whole image (whole bands per XCD would leave the cheapest band's XCD idle).
+    const int nB = P.xBB64 * P.yBB64;
+    const int slot = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int grp = slot / YK2_RUN;
+    const int L = (grp * 8 + ((xcd + grp) & 7)) * YK2_RUN + (slot - grp * YK2_RUN);   // rotate so no XCD is tied to one image column band
+    if (L >= nB) return;
+    const int BY = L / P.xBB64, BX = L - BY * P.xBB64;
     const int w = P.w, h = P.h;
 
     if (tid < 24) s_bm[tid] = 0;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
             for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
         }
     } else {
-        uint16_t* lut = &s_lut[wave][tw][0];
+        uint32_t* lut = &s_lut[wave][tw][0];
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
         for (int p = 0; p < 3; p++) {
             // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
@@ -293,28 +309,37 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
             const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
             const int rangeDecode = (dist * scale) / 127 + 32;
             const float Rf = (float)rangeDecode, BNf = (float)BN;
-            // the four lanes of the tile build the 72 LUT entries: lane j4 takes entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit)
+            // the four lanes of the tile build the 72 LUT entries: lane j4 takes entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit).
+            // The curves are non-decreasing and Rf > 0, so every LUT is sorted: the first nearest entry of a pixel lies in the
+            // quarter selected by the midpoints between quarters (ties go to the lower quarter, like the reference's first-min scan).
 #pragma unroll
-            for (int m = 0; m < 3; m++)
+            for (int m = 0; m < 3; m++) {
+                uint32_t L[5];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    lut[m * 16 + j4 * 4 + k] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 4 + k], Rf))) << 4);
+                for (int k = 0; k < 5; k++)
+                    L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][min(j4 * 4 + k, 15)], Rf)));
+                *reinterpret_cast<uint4*>(&lut[m * 20 + j4 * 4]) = make_uint4(L[0] << 8, L[1] << 8, L[2] << 8, L[3] << 8);
+                if (j4 < 3) lut[m * 20 + 16 + j4] = (L[3] + L[4]) << 7;
+            }
 #pragma unroll
-            for (int m = 3; m < 6; m++)
+            for (int m = 3; m < 6; m++) {
+                uint32_t L[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++)
-                    lut[48 + (m - 3) * 8 + j4 * 2 + k] = (uint16_t)(__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf))) << 4);
+                    L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf)));
+                *reinterpret_cast<uint2*>(&lut[60 + (m - 3) * 8 + j4 * 2]) = make_uint2(L[0] << 8, L[1] << 8);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            // v<<4 per pixel and a FAST reciprocal (v_rcp_f32, <= 1 ulp): the screening sums below only need ~1e-7 relative
+            // v<<8 per pixel and a FAST reciprocal (v_rcp_f32, <= 1 ulp): the screening sums below only need ~1e-7 relative
             // accuracy per term; the exact terms (IEEE division) are recomputed in the rare fallback.
             uint32_t vs[16]; float rv[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int v = y2_byte(pw[k], p);
-                vs[k] = (uint32_t)v << 4;
+                vs[k] = (uint32_t)v << 8;
                 rv[k] = (valid && v != 0) ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // r = 0 -> the term is exactly +0 (skipped pixel)
             }
             // The reference adds the 64 exact terms minDiff/v SEQUENTIALLY in float (:885) and, walking the modes in order, keeps
@@ -331,22 +356,35 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
 #pragma unroll
             for (int m = 0; m < 6; m++) {
                 if (m >= P.startMode && !(P.ablate & 4)) {
-                    const int cnt = m < 3 ? 16 : 8;
-                    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8));
-                    uint32_t e[16];
-#pragma unroll
-                    for (int k = 0; k < cnt / 2; k++) { const uint32_t wv = lw[k]; e[2 * k] = wv & 0xFFFFu; e[2 * k + 1] = wv >> 16; }
+                    // key = (minDiff << 8) | index of the first nearest entry (:873-881): v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n
+                    const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
+                    uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
+                    if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
+                    else {
+                        const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
+                        e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+                    }
                     float s = 0.0f;
                     uint32_t mLo = 0, mHi = 0, mMd[4] = { 0, 0, 0, 0 };
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        uint32_t key = 0xFFFFFFFFu;
+                        const uint32_t x = vs[k];
+                        uint32_t key;
+                        if (m < 3) {
+                            const bool c2 = x > H2;
+                            const bool c1 = x > (c2 ? H3 : H1);
+                            const uint32_t qd = (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
+                            const uint4 E = *reinterpret_cast<const uint4*>(lm + qd * 4);
+                            key = min(min(y2_absdiff(E.x, x), __usad(E.y, x, 1u)), min(__usad(E.z, x, 2u), __usad(E.w, x, 3u))) + qd * 4u;
+                        } else {
+                            key = y2_absdiff(e[0], x);
 #pragma unroll
-                        for (int n = 0; n < cnt; n++) key = min(key, __usad(e[n], vs[k], n));          // first nearest entry (:873-881)
-                        const uint32_t md = key >> 4;
-                        if (k < 8) mLo |= (key & 15u) << (4 * k); else mHi |= (key & 15u) << (4 * (k - 8));
-                        mMd[k >> 2] |= md << (8 * (k & 3));
-                        s = __fadd_rn(s, __fmul_rn((float)(int)md, rv[k]));
+                            for (int n = 1; n < 8; n++) key = min(key, __usad(e[n], x, (uint32_t)n));
+                        }
+                        // pixel k's index nibble / minDiff byte enter at the top and shift down: after 8 (4) pixels pixel 0 sits lowest
+                        if (k < 8) mLo = __builtin_amdgcn_alignbit(key, mLo, 4); else mHi = __builtin_amdgcn_alignbit(key, mHi, 4);
+                        mMd[k >> 2] = __builtin_amdgcn_perm(key, mMd[k >> 2], 0x05030201u);
+                        s = __fmaf_rn((float)((key >> 8) & 255u), rv[k], s);
                     }
                     s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
                     bool take;
@@ -376,7 +414,7 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
                 ambMask &= ~(0x33ULL << a00);
                 if (l00 == a00) {                                            // the four lanes of the tile publish their exact terms in pixel order
                     for (int m = P.startMode; m < 6; m++) {
-                        const uint16_t* lm = lut + (m < 3 ? m * 16 : 48 + (m - 3) * 8);
+                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
                         const int cnt = m < 3 ? 16 : 8;
                         for (int r = 0; r < 4; r++) {
                             float qv[4];
@@ -387,9 +425,9 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
 #pragma unroll
                                 for (int kk = 0; kk < 16; kk++) v4 = (kk == k) ? vs[kk] : v4;
                                 uint32_t key = 0xFFFFFFFFu;
-                                for (int n = 0; n < cnt; n++) key = min(key, __usad((uint32_t)lm[n], v4, (uint32_t)n));
-                                const int v = (int)(v4 >> 4);
-                                qv[i] = (valid && v != 0) ? __fdiv_rn((float)(int)(key >> 4), (float)v) : 0.0f;      // divss (:885)
+                                for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], v4, (uint32_t)n));
+                                const int v = (int)(v4 >> 8);
+                                qv[i] = (valid && v != 0) ? __fdiv_rn((float)(int)(key >> 8), (float)v) : 0.0f;      // divss (:885)
                             }
                             *reinterpret_cast<float4*>(&s_chain[wave][m][(cyl * 4 + r) * 8 + cxl * 4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
                         }
@@ -416,13 +454,13 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
                         const float e = s_err[wave][m];
                         if (e <= bestErr) { bestErr = e; bestMode = m; }
                     }
-                    const uint16_t* lm = lut + (bestMode < 3 ? bestMode * 16 : 48 + (bestMode - 3) * 8);
+                    const uint32_t* lm = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
                     const int cnt = bestMode < 3 ? 16 : 8;
                     cLo = 0; cHi = 0;
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         uint32_t key = 0xFFFFFFFFu;
-                        for (int n = 0; n < cnt; n++) key = min(key, __usad((uint32_t)lm[n], vs[k], (uint32_t)n));
+                        for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], vs[k], (uint32_t)n));
                         if (k < 8) cLo |= (key & 15u) << (4 * k); else cHi |= (key & 15u) << (4 * (k - 8));
                     }
                 }
@@ -439,10 +477,10 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
                     const uint32_t code16 = ((r < 2 ? cLo : cHi) >> (16 * (r & 1))) & 0xFFFFu;
                     *reinterpret_cast<uint16_t*>(slot + (pos >> 1)) = (uint16_t)code16;
                     if (P.wantDst) {
-                        const uint16_t* lb = lut + (bestMode < 3 ? bestMode * 16 : 48 + (bestMode - 3) * 8);
+                        const uint32_t* lb = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
                         int32_t* drow = P.dst[p] + (size_t)(gyCell + r) * w + gxCell;
 #pragma unroll
-                        for (int i = 0; i < 4; i++) drow[i] = (int32_t)(lb[(code16 >> (4 * i)) & 15u] >> 4);
+                        for (int i = 0; i < 4; i++) drow[i] = (int32_t)(lb[(code16 >> (4 * i)) & 15u] >> 8);
                     }
                 }
             }
@@ -487,7 +525,8 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
 }
 
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
-    dim3 grid(P.xBB64, P.yBB64);
+    const int group = 8 * YK2_RUN;
+    dim3 grid(((P.xBB64 * P.yBB64 + group - 1) / group) * group);
     hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(256), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
