@@ -119,7 +119,7 @@ def main() -> int:
     mpix = W * W * world * args.steps / 1e6
     value = mpix / elapsed
 
-    # ---- roofline of the dominant kernel (yk_encode_kernel): algorithmic bytes / event-timed duration -------------
+    # ---- roofline of the dominant kernel (yk_encode2_kernel): algorithmic bytes / event-timed duration -------------
     nd_nn = [enc.range_streams(p) for p in range(3)]
     bitmap_bytes = sum(enc.gradient_bitmap(p).size for p in range(7))
     out_bytes = sum(2 * d.size + nb.size for d, nb, _ in nd_nn)
@@ -127,8 +127,8 @@ def main() -> int:
     achieved = alg_bytes / (kms["encode"] * 1e-3) / 1e9 if kms["encode"] > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "yk_encode_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
-                "other_kernels_ms": {"yk_alpha_kernel": round(kms["alpha"], 4), "scan+pack": round(kms["pack"], 4)}}
+                "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
+                "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (4 kernels)": round(kms["pack"], 4)}}
 
     result = {
         "metric": "Mpix/s tile encode (alpha reject + 7 gradient passes + 8x8 range quant), 8K RGBA",

@@ -124,12 +124,16 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lc
 #define YK2_RUN 16
 #define YK2_LUTW 84
 
-__global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_pix[YK_LROWS * LS];
+__global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams P) {
+    // The staged pixels are only read by the gradient passes (afterwards every lane holds its 16 pixels in registers), so the
+    // range quantiser's LUTs reuse the same LDS behind a workgroup barrier: 28 KB per workgroup instead of 46 KB.
+    // LUT layout per wave, per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19);
+    // 3-bit mode m at [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint, same units).
+    constexpr int kPixWords = YK_LROWS * LS, kLutWords = 4 * 16 * YK2_LUTW;
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kPixWords > kLutWords ? kPixWords : kLutWords];
+    uint32_t* const s_pix = s_mem;
+    uint32_t (*const s_lut)[16][YK2_LUTW] = reinterpret_cast<uint32_t (*)[16][YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
-    // per wave, per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19); 3-bit mode m at
-    // [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint in the same units).
-    __shared__ __attribute__((aligned(16))) uint32_t s_lut[4][16][YK2_LUTW];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
     __shared__ __attribute__((aligned(16))) float s_chain[4][6][68];        // exact-order fallback, one tile-plane at a time per wave
     __shared__ float s_err[4][8];
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256) void yk_encode2_kernel(const YkEncodeParams P)
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
     if (cell == 0 && mtIn) P.coverage[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
 
+    __syncthreads();                                                         // s_pix is dead from here on: its LDS becomes s_lut
     // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
     if (P.bounds) {
