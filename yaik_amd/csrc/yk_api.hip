@@ -42,6 +42,7 @@ int yk_create(int device, yk_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return YK_ERR_NO_DEVICE;
     yk_ctx* c = new yk_ctx();
     c->device = device;
+    if (hipDeviceGetAttribute(&c->numCU, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->numCU <= 0) c->numCU = 256;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return YK_ERR_HIP; }
     c->stream = c->ownStream;
     for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return YK_ERR_HIP; }

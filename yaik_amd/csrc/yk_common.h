@@ -36,6 +36,7 @@ struct YkEncodeParams {
 
 struct yk_ctx {
     int device = -1;
+    int numCU = 256;             // compute units of the device (persistent grids are sized from it)
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;

@@ -124,44 +124,49 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lc
 #define YK2_RUN 16
 #define YK2_LUTW 84
 
-__global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams P) {
-    // The staged pixels are only read by the gradient passes (afterwards every lane holds its 16 pixels in registers), so the
-    // range quantiser's LUTs reuse the same LDS behind a workgroup barrier: 28 KB per workgroup instead of 46 KB.
-    // LUT layout per wave, per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19);
+__global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams P) {
+    // One wave64 per workgroup: a work unit is a 64x16 strip (four macro-tiles) of a 64x64 swizzle block, so nothing in the
+    // kernel waits on another wave.  The staged pixels are only read by the gradient passes (afterwards every lane holds its
+    // 16 pixels in registers), so the range quantiser's LUTs reuse the same LDS.
+    // LUT layout per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19);
     // 3-bit mode m at [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint, same units).
-    constexpr int kPixWords = YK_LROWS * LS, kLutWords = 4 * 16 * YK2_LUTW;
+    constexpr int kPixWords = 17 * LS, kLutWords = 16 * YK2_LUTW;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kPixWords > kLutWords ? kPixWords : kLutWords];
     uint32_t* const s_pix = s_mem;
-    uint32_t (*const s_lut)[16][YK2_LUTW] = reinterpret_cast<uint32_t (*)[16][YK2_LUTW]>(s_mem);
+    uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
-    __shared__ __attribute__((aligned(16))) float s_chain[4][6][68];        // exact-order fallback, one tile-plane at a time per wave
-    __shared__ float s_err[4][8];
+    __shared__ __attribute__((aligned(16))) float s_chain[6][68];           // exact-order fallback, one tile-plane at a time
+    __shared__ float s_err[8];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware block order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Blocks are
-    // taken in row-major runs of YK2_RUN; XCD k gets the k-th run of every group of 8 runs, so the halo column of a block is a
-    // line its right-hand neighbour streams through the same L2 at about the same time instead of a second fabric fetch,
-    // while every XCD still samples the whole image (whole bands per XCD would leave the cheapest band's XCD idle).
+    const int lane = threadIdx.x;
+    // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
+    // taken in row-major runs of YK2_RUN blocks (4 strips each); XCD k gets a rotating run of every group of 8 runs, so the
+    // halo column of a block and the halo row of a strip are lines a neighbour streams through the same L2 at about the same
+    // time instead of a second fabric fetch, while every XCD still samples the whole image (whole bands per XCD would leave
+    // the cheapest band's XCD idle).
     const int nB = P.xBB64 * P.yBB64;
     const int slot = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
-    const int grp = slot / YK2_RUN;
-    const int L = (grp * 8 + ((xcd + grp) & 7)) * YK2_RUN + (slot - grp * YK2_RUN);   // rotate so no XCD is tied to one image column band
+    const int grp = slot / (YK2_RUN * 4);
+    const int unit = (grp * 8 + ((xcd + grp) & 7)) * (YK2_RUN * 4) + (slot - grp * (YK2_RUN * 4));
+    const int L = unit >> 2, wave = unit & 3;                                // block (row-major) and strip inside the block
     if (L >= nB) return;
     const int BY = L / P.xBB64, BX = L - BY * P.xBB64;
     const int w = P.w, h = P.h;
 
-    if (tid < 24) s_bm[tid] = 0;
-    if (tid < 96) s_curve[tid >> 4][tid & 15] = c_curve2[tid >> 4][tid & 15];
-    // ---- stage the clamped 65x65 block (Plane::GetPixelValue clamp, encoder/framework.h:116-121); all loads first ------
+    if (lane < 24) s_bm[lane] = 0;
+    s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
+    if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
+    // ---- stage the clamped 65x17 strip (Plane::GetPixelValue clamp, encoder/framework.h:116-121); all loads first ------
     {
-        const int g4 = (tid & 15) * 4, r0 = tid >> 4;
+        const int g4 = (lane & 15) * 4, r0 = lane >> 4;
         const int gx = BX * 64 + g4;
         const bool inX = gx + 3 < w;
+        const int gyS = BY * 64 + wave * 16;
         int4 R[4], G[4], B[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int gy = min(BY * 64 + r0 + 16 * k, P.hAvail - 1);
+            const int gy = min(gyS + r0 + 4 * k, P.hAvail - 1);
             if (inX) {
                 const size_t off = (size_t)gy * P.strideElems + gx;
                 R[k] = *reinterpret_cast<const int4*>(P.plane[0] + off);
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
             }
         }
         int4 Rb = make_int4(0, 0, 0, 0), Gb = Rb, Bb = Rb;
-        if (tid < 16) {
-            const int gy = min(BY * 64 + 64, P.hAvail - 1);
+        if (lane < 16) {
+            const int gy = min(gyS + 16, P.hAvail - 1);
             if (inX) {
                 const size_t off = (size_t)gy * P.strideElems + gx;
                 Rb = *reinterpret_cast<const int4*>(P.plane[0] + off);
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
             }
         }
         uint32_t hcol = 0;
-        const int hr = tid - 64;
-        if (hr >= 0 && hr < YK_LROWS) {
-            const int gy = min(BY * 64 + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
+        const int hr = lane - 32;
+        if (hr >= 0 && hr < 17) {
+            const int gy = min(gyS + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
             const size_t off = (size_t)gy * P.strideElems + gxh;
             hcol = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
         }
@@ -200,24 +205,24 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
                                        (uint32_t)R[k].y | ((uint32_t)G[k].y << 8) | ((uint32_t)B[k].y << 16),
                                        (uint32_t)R[k].z | ((uint32_t)G[k].z << 8) | ((uint32_t)B[k].z << 16),
                                        (uint32_t)R[k].w | ((uint32_t)G[k].w << 8) | ((uint32_t)B[k].w << 16));
-            *reinterpret_cast<uint4*>(&s_pix[(r0 + 16 * k) * LS + g4]) = o;
+            *reinterpret_cast<uint4*>(&s_pix[(r0 + 4 * k) * LS + g4]) = o;
         }
-        if (tid < 16) {
+        if (lane < 16) {
             const uint4 o = make_uint4((uint32_t)Rb.x | ((uint32_t)Gb.x << 8) | ((uint32_t)Bb.x << 16),
                                        (uint32_t)Rb.y | ((uint32_t)Gb.y << 8) | ((uint32_t)Bb.y << 16),
                                        (uint32_t)Rb.z | ((uint32_t)Gb.z << 8) | ((uint32_t)Bb.z << 16),
                                        (uint32_t)Rb.w | ((uint32_t)Gb.w << 8) | ((uint32_t)Bb.w << 16));
-            *reinterpret_cast<uint4*>(&s_pix[64 * LS + g4]) = o;
+            *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = o;
         }
-        if (hr >= 0 && hr < YK_LROWS) s_pix[hr * LS + 64] = hcol;
+        if (hr >= 0 && hr < 17) s_pix[hr * LS + 64] = hcol;
     }
-    __syncthreads();
+    __syncthreads();                                                         // single-wave workgroup: an LDS fence
 
     // ---- lane geometry: wave = macro-tile row `wave` of the block, lane = macroTile(q)*16 + cellY*4 + cellX ------------
     const int q = lane >> 4, cell = lane & 15, cx = cell & 3, cy = cell >> 2;
     const int bxCell = q * 16 + cx * 4, byCell = wave * 16 + cy * 4;          // cell origin inside the block
     const int gxCell = BX * 64 + bxCell, gyCell = BY * 64 + byCell;          // stripe-local pixels
-    const int lcell = byCell * LS + bxCell;
+    const int lcell = (cy * 4) * LS + bxCell;                                // strip-local LDS word of the cell origin
     const bool mtIn = (BX * 64 + q * 16 < w) && (BY * 64 + wave * 16 < h);    // macro-tile origin inside the image
 
     uint32_t pw[16];
@@ -259,7 +264,29 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
     if (cell == 0 && mtIn) P.coverage[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
 
-    __syncthreads();                                                         // s_pix is dead from here on: its LDS becomes s_lut
+    // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
+    // strip's tiles into whole bytes of the block's words except 16x16 (4 bits per strip), which is OR-ed into a pre-zeroed map.
+    __syncthreads();                                                         // fence: s_bm complete; s_pix dead, its LDS becomes s_lut
+    if (lane == 0) {
+        const int i64 = BY * P.xBB64 + BX;
+        const uint32_t nib = (s_bm[0] >> (4 * wave)) & 0xFu;
+        if (nib) atomicOr(reinterpret_cast<uint32_t*>(P.bitmap[0]) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave));
+        P.bitmap[1][i64 * 4 + wave] = (uint8_t)(s_bm[1] >> (8 * wave));                                          // 16x8: tile rows 2w, 2w+1
+        P.bitmap[2][i64 * 4 + wave] = (uint8_t)(s_bm[2] >> (8 * wave));                                          // 8x16: tile row w
+        reinterpret_cast<uint16_t*>(P.bitmap[3])[i64 * 4 + wave] = (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1)));   // 8x8: rows 2w, 2w+1
+        {
+            const int sb = wave >> 1;                                        // 8x4: 64x32 swizzle blocks, tile rows 4w..4w+3 = one dword
+            if (BY * 2 + sb < P.yBB32) reinterpret_cast<uint32_t*>(P.bitmap[4])[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)] = s_bm[5 + sb * 2 + (wave & 1)];
+        }
+        for (int sx = 0; sx < 2; sx++) {
+            if (BX * 2 + sx < P.xBB32) {
+                // 4x8: 32x64 swizzle blocks, tile rows 2w, 2w+1 = one u16;  4x4: 32x32 swizzle blocks, tile rows 4w..4w+3 = one dword
+                reinterpret_cast<uint16_t*>(P.bitmap[5])[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave] = (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1)));
+                const int sy = wave >> 1;
+                if (BY * 2 + sy < P.yBB32) reinterpret_cast<uint32_t*>(P.bitmap[6])[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)] = s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)];
+            }
+        }
+    }
     // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
     if (P.bounds) {
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
             for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
         }
     } else {
-        uint32_t* lut = &s_lut[wave][tw][0];
+        uint32_t* lut = &s_lut[tw][0];
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
         for (int p = 0; p < 3; p++) {
             // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
                                 const int v = (int)(v4 >> 8);
                                 qv[i] = (valid && v != 0) ? __fdiv_rn((float)(int)(key >> 8), (float)v) : 0.0f;      // divss (:885)
                             }
-                            *reinterpret_cast<float4*>(&s_chain[wave][m][(cyl * 4 + r) * 8 + cxl * 4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+                            *reinterpret_cast<float4*>(&s_chain[m][(cyl * 4 + r) * 8 + cxl * 4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
                         }
                     }
                 }
@@ -443,12 +470,12 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (lane < 6 && lane >= P.startMode) {                       // errorDist += minDiff / v in row-major pixel order (:885)
                     float s = 0.0f;
-                    const float4* cp = reinterpret_cast<const float4*>(&s_chain[wave][lane][0]);
+                    const float4* cp = reinterpret_cast<const float4*>(&s_chain[lane][0]);
                     for (int k = 0; k < 16; k++) {
                         const float4 a = cp[k];
                         s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, a.x), a.y), a.z), a.w);
                     }
-                    s_err[wave][lane] = s;
+                    s_err[lane] = s;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
                 if (l00 == a00) {                                            // last mode whose error is <= the best so far (:897-905)
                     bestMode = -1; float bestErr = 99999999.0f;
                     for (int m = P.startMode; m < 6; m++) {
-                        const float e = s_err[wave][m];
+                        const float e = s_err[m];
                         if (e <= bestErr) { bestErr = e; bestMode = m; }
                     }
                     const uint32_t* lm = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
@@ -498,41 +525,13 @@ __global__ __launch_bounds__(256, 4) void yk_encode2_kernel(const YkEncodeParams
         }
     }
 
-    // ---- block bitmaps -> the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805) -----------
-    __syncthreads();
-    if (tid == 0) {
-        const int i64 = BY * P.xBB64 + BX;
-        reinterpret_cast<uint16_t*>(P.bitmap[0])[i64] = (uint16_t)s_bm[0];
-        reinterpret_cast<uint32_t*>(P.bitmap[1])[i64] = s_bm[1];
-        reinterpret_cast<uint32_t*>(P.bitmap[2])[i64] = s_bm[2];
-        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2] = s_bm[3];
-        reinterpret_cast<uint32_t*>(P.bitmap[3])[i64 * 2 + 1] = s_bm[4];
-        for (int s = 0; s < 2; s++) {
-            if (BY * 2 + s < P.yBB32) {
-                const int i = (BY * 2 + s) * P.xBB64 + BX;
-                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2] = s_bm[5 + s * 2];
-                reinterpret_cast<uint32_t*>(P.bitmap[4])[i * 2 + 1] = s_bm[6 + s * 2];
-            }
-            if (BX * 2 + s < P.xBB32) {
-                const int i = BY * P.xBB32 + BX * 2 + s;
-                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2] = s_bm[9 + s * 2];
-                reinterpret_cast<uint32_t*>(P.bitmap[5])[i * 2 + 1] = s_bm[10 + s * 2];
-            }
-        }
-        for (int sy = 0; sy < 2; sy++) for (int sx = 0; sx < 2; sx++) {
-            if (BY * 2 + sy < P.yBB32 && BX * 2 + sx < P.xBB32) {
-                const int i = (BY * 2 + sy) * P.xBB32 + BX * 2 + sx;
-                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2] = s_bm[13 + (sy * 2 + sx) * 2];
-                reinterpret_cast<uint32_t*>(P.bitmap[6])[i * 2 + 1] = s_bm[14 + (sy * 2 + sx) * 2];
-            }
-        }
-    }
 }
 
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
-    const int group = 8 * YK2_RUN;
-    dim3 grid(((P.xBB64 * P.yBB64 + group - 1) / group) * group);
-    hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(256), 0, c->stream, P);
+    const int nB = P.xBB64 * P.yBB64, group = 8 * YK2_RUN;
+    YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, ((size_t)nB * 2 + 3) & ~(size_t)3, c->stream));    // 16x16 map: strips OR their 4 bits in
+    dim3 grid(((nB + group - 1) / group) * group * 4);
+    hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(64), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
