@@ -125,8 +125,16 @@ def main() -> int:
     out_bytes = sum(2 * d.size + nb.size for d, nb, _ in nd_nn)
     alg_bytes = 12 * W * W + bitmap_bytes + out_bytes            # 4 B x 3 planes read once + bitmaps + defs + nibbles
     achieved = alg_bytes / (kms["encode"] * 1e-3) / 1e9 if kms["encode"] > 0 else 0.0
+    # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh); only valid for the default workload
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    if os.path.exists(tpath) and W == 8192 and not args.mode3:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("kernel") == "yk_encode2_kernel":
+            traffic, traffic_src = int(tj["hbm_traffic_bytes"]), tj.get("source")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
                 "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (4 kernels)": round(kms["pack"], 4)}}
 
