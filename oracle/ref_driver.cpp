@@ -204,6 +204,18 @@ int main(int argc, char** argv) {
     blob("d1_type", types.data(), ends[5]);
     blob("d1_ends", ends, sizeof ends);
     for (int p = 0; p < 3; p++) blobPlane16(nm("d1_out", p), out1d->GetPlane(p));
+    // '1DTL' chunk of the three planes (EncoderContext.cpp:8524-8576), then everything the passes appended to outFile so far:
+    // ['MIPM'] 7x['GTIL'] 6x'PLNT' '1DTL' exactly as the reference framed them (ZStd 1.3.4 payloads).
+    ctx->GenerateDynamicTileChunk(pix.data(), ends[2]);
+    {
+        fflush(ctx->outFile);
+        long all = ftell(ctx->outFile);
+        std::vector<u8> file(all);
+        fseek(ctx->outFile, 0, SEEK_SET);
+        if (all && fread(file.data(), 1, file.size(), ctx->outFile) != file.size()) return 2;
+        fseek(ctx->outFile, all, SEEK_SET);
+        blob("chunks_file", file.data(), file.size());
+    }
 
     // ---- a16/a17 decode loops on a hand-filled YAIK_Instance (allocation rule: decoder/YAIK_API.cpp:650-657, :855-874) ----
     YAIK_Instance inst; memset(&inst, 0, sizeof inst);

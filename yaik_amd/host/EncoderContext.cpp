@@ -4,13 +4,15 @@
 #include "EncoderContext.h"
 #include <climits>
 #include "../../include/yaik_hip.h"
+#include "chunks.h"
+#include "palette.h"
 
 static const int kPass[7][2] = { {4, 4}, {4, 3}, {3, 4}, {3, 3}, {3, 2}, {2, 3}, {2, 2} };      // EncoderContext.cpp:9057-9093
 
 EncoderContext::EncoderContext()
     : colorCompressionQuad(250), colorCompressionLUT3D(250), colorCompression1D(255), rangeCompression1D(15),
       mipMapTileSize(16), boundX0(0), boundY0(0), boundX1(0), boundY1(0), remainingPixels(0),
-      dumpImage(false), evaluateLUT(false), evaluateLUT2D(false), outFile(nullptr), device(0),
+      dumpImage(false), evaluateLUT(false), evaluateLUT2D(false), outFile(nullptr), fileOutSize(0), device(0),
       original(nullptr), ctx(nullptr), bound(false), alphaDone(false), encoded(false), enc3(false), encDst(false), oneDReady(false),
       encReject(3), nextPass(0), nNibbles(0), cursor1d(0), mipHasChunk(false) {}
 
@@ -65,6 +67,10 @@ void EncoderContext::MipPrefilter(bool /*active*/) {
         size_t nb = 0;
         if (yk_alpha_bitmap(ctx, mipBitmap.data(), mipBitmap.size(), &nb) != YK_OK) { fail("yk_alpha_bitmap"); return; }
         mipBitmap.resize(nb);
+        if (outFile) {                                                     // 'MIPM' chunk, mipmapLevel = maxMipLevel + 1 = 4 (:1367-1396)
+            const int tbi[4] = { tb[0], tb[1], tb[2], tb[3] };
+            if (!yaikchunk::writeMipmap(outFile, tbi, 4, mipBitmap.data(), mipBitmap.size())) { fail("MipPrefilter: fwrite"); return; }
+        }
     }
     alphaDone = true; encoded = false; nextPass = 0;
 }
@@ -98,6 +104,13 @@ int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plan
     gradRgb.resize(cap);
     if (yk_gradient_corners(ctx, pass, gradRgb.data(), cap, &nb) != YK_OK) { fail("yk_gradient_corners"); return 0; }
     gradRgb.resize(nb);
+    if (outFile && !evaluateLUT) {                                         // 'GTIL' chunk (:4239-4347), full RGB pass: PlaneBit 7
+        std::string e;
+        const long before = ftell(outFile);
+        if (yaikchunk::writeGradientTile(outFile, original->GetWidth(), original->GetHeight(), tileBitSizeX, tileBitSizeY, gradBitmap.data(),
+                                         gradBitmap.size(), gradRgb.data(), gradRgb.size(), colorCompressionQuad, 7, e) < 0) { fail(("FittingQuadSmooth: " + e).c_str()); return 0; }
+        fileOutSize += (int)(ftell(outFile) - before);
+    }
     int tiles = 0;
     for (u8 v : gradBitmap) tiles += __builtin_popcount(v);               // TileDone (:4362)
     return tiles;
@@ -121,6 +134,13 @@ int EncoderContext::DynamicTileEncode(bool mode3BitOnly, Plane* plane, Plane* ds
         int* d = dst->GetPixels();
         for (size_t i = 0; i < n; i++) if (tmp[i] != INT_MIN) d[i] = tmp[i];
     }
+    if (outFile) {                                                         // 'PLNT' chunk (:4516-4589); constraint = 8-aligned bound box (:4386-4391)
+        BoundingBox cb;
+        cb.x = (s16)((boundX0 >> 3) << 3); cb.y = (s16)((boundY0 >> 3) << 3);
+        cb.w = (s16)((((boundX1 + 7) >> 3) << 3) - cb.x); cb.h = (s16)((((boundY1 + 7) >> 3) << 3) - cb.y);
+        std::string e;
+        if (!yaikchunk::writePlaneTile(outFile, cb, tileDefs.data(), tileDefs.size(), tileIdx.data(), tileIdx.size(), 0, false, false, e)) { fail(("DynamicTileEncode: " + e).c_str()); return 0; }
+    }
     return 0;                                                              // the reference returns layerSize, which it never updates (:4407,:4601)
 }
 
@@ -141,4 +161,35 @@ u8* EncoderContext::DynamicTileCompressor(u8* stream, Plane* src, Plane* /*map*/
     const size_t per = pix1d.size() / 3;                                   // coverage is shared by the three planes
     memcpy(stream, pix1d.data() + per * p, per);
     return stream + per;
+}
+
+void EncoderContext::GenerateDynamicTileChunk(u8* stream, int sizeStream) {
+    if (!outFile || sizeStream <= 0) return;
+    std::string e;
+    if (!yaikchunk::writeTile1D(outFile, stream, (size_t)sizeStream, type1d.data(), type1d.size(), colorCompression1D, rangeCompression1D, e))
+        fail(("GenerateDynamicTileChunk: " + e).c_str());
+}
+
+bool EncoderContext::ConvertHotPath(FILE* f) {
+    if (!bound || !f) return fail("ConvertHotPath: SetImageToEncode and an open file first");
+    FILE* saved = outFile; outFile = f; fileOutSize = 0; err.clear();
+    PaletteResetCodeBook();                             // the reference converts one image per process: its code table starts zeroed
+    const int w = original->GetWidth(), h = original->GetHeight();
+    bool ok = yaikchunk::writeFileHeader(f, w, h, original->HasAlpha());
+    if (ok && original->HasAlpha()) MipPrefilter(true);
+    PrepareQuadSmooth();
+    for (int i = 0; ok && i < 7; i++) {
+        FittingQuadSmooth(3, original->GetPlane(0), original->GetPlane(1), original->GetPlane(2), nullptr, false, kPass[i][0], kPass[i][1]);
+        ok = err.empty();
+    }
+    if (ok) {
+        std::vector<u8> stream((size_t)w * h * 3 + 64);
+        u8* wr = stream.data();
+        for (int p = 0; p < 3; p++) wr = DynamicTileCompressor(wr, original->GetPlane(p), nullptr, nullptr);
+        GenerateDynamicTileChunk(stream.data(), (int)(wr - stream.data()));
+        ok = err.empty();
+    }
+    ok = ok && yaikchunk::writeEndOfFile(f);
+    outFile = saved;
+    return ok;
 }

@@ -2,9 +2,10 @@
 // same method names, argument meaning and call order for MipPrefilter -> 7x FittingQuadSmooth -> DynamicTileEncode x3
 // (-> DynamicTileCompressor x3), executed on an MI355X through the C-ABI of include/yaik_hip.h.
 //
-// Differences a caller sees (all consequences of "the entropy stage stays on host cores, outside this path"):
-//   * the passes do not fwrite chunks to `outFile`; the raw streams each pass hands to ZStd / PaletteCompressor in the
-//     reference are exposed through the Last*() accessors instead (bitmap, corner stream, tile defs, nibble stream);
+// Differences a caller sees:
+//   * with `outFile` set the passes append the same chunks as the reference ('MIPM', 'GTIL', 'PLNT', '1DTL'; PaletteCompressor
+//     and ZStd run on host cores, see chunks.h); with `outFile == NULL` they write nothing.  Either way the raw streams each
+//     pass hands to the entropy stage are exposed through the Last*() accessors (bitmap, corner stream, tile defs, nibbles);
 //   * the seven FittingQuadSmooth calls must come in the shipped order (4,4)(4,3)(3,4)(3,3)(3,2)(2,3)(2,2) with the image's
 //     planes 0,1,2 (EncoderContext.cpp:9057-9093): the first one launches the fused kernel, the others return its cached results;
 //   * errors follow the reference's convention (message on stdout, neutral return value) plus LastError().
@@ -27,7 +28,8 @@ public:
     // mipmap-mask bounding box in pixels + bookkeeping the range quantiser reads (EncoderContext.h:246-253)
     int mipMapTileSize, boundX0, boundY0, boundX1, boundY1, remainingPixels;
     bool dumpImage, evaluateLUT, evaluateLUT2D;
-    FILE* outFile;                                      // kept for source compatibility; never written by this path
+    FILE* outFile;                                      // chunks are appended here when set (the reference requires it; NULL = streams only)
+    int fileOutSize;
 
     bool SetImageToEncode(Image* newImage);             // takes ownership, deletes the previous image (EncoderContext.cpp:1227-1233)
     void Release();
@@ -39,6 +41,10 @@ public:
                            int tileBitSizeX, int tileBitSizeY);                           // :3710, returns TileDone
     int  DynamicTileEncode(bool mode3BitOnly, Plane* plane, Plane* dst, bool isCo, bool isCg, bool isHalfX, bool isHalfY);   // :4365
     u8*  DynamicTileCompressor(u8* stream, Plane* src, Plane* map, Plane* debug);         // :8398, returns the advanced cursor
+    void GenerateDynamicTileChunk(u8* stream, int sizeStream);                            // :8524, '1DTL' chunk of the three planes' streams
+    // The chunk sequence of Convert() restricted to this path (:9007-9016, :9057-9093, :9451-9470, :9779-9781): file header,
+    // ['MIPM' for RGBA], 7x 'GTIL', '1DTL', terminator — a stream the reference's YAIK_DecodeImage accepts.  Takes no ownership of f.
+    bool ConvertHotPath(FILE* f);
 
     // raw streams of the last call of each kind (what the reference compresses and writes, before entropy coding)
     const std::vector<u8>&  LastGradientBitmap() const { return gradBitmap; }             // pFillBitMap (:3775)

@@ -2,12 +2,15 @@
 // (encoder/ImageEncoder.cpp:158-213 / EncoderContext::Convert): same call sequence, same method names, but linked against
 // the MI355X drop-in.  tests/test_gpu_host_mirror.py checks its output blob by blob.
 //
-// usage: host_driver <in.bin> <out.blobs> [mode3BitOnly]
+// usage: host_driver <in.bin> <out.blobs> [mode3BitOnly] [out.yaik]
+// With the 4th argument the image is also converted to a .yaik stream (ConvertHotPath) and decoded back through the
+// YAIK_* decoder API, the way an application would use the two libraries.
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
 #include "EncoderContext.h"
+#include "yaik_decode.h"
 
 static FILE* gOut;
 static void blob(const std::string& name, const void* data, size_t len) {
@@ -29,6 +32,8 @@ int main(int argc, char** argv) {
 
     EncoderContext* ctx = new EncoderContext();
     if (!ctx->SetImageToEncode(img)) { fprintf(stderr, "%s\n", ctx->LastError()); return 3; }
+    ctx->outFile = tmpfile();                                      // the passes append their chunks here, like the reference's outFile
+    if (!ctx->outFile) return 2;
     if (np == 4) {
         ctx->MipPrefilter(true);
         int b[6] = { ctx->boundX0, ctx->boundY0, ctx->boundX1, ctx->boundY1, ctx->mipMapTileSize, ctx->remainingPixels };
@@ -61,6 +66,55 @@ int main(int argc, char** argv) {
     for (int p = 0; p < 3; p++) wr = ctx->DynamicTileCompressor(wr, img->GetPlane(p), nullptr, nullptr);
     blob("d1_pix", pix.data(), (size_t)(wr - pix.data()));
     blob("d1_type", ctx->TileTypeStream1D().data(), ctx->TileTypeStream1D().size());
+    ctx->GenerateDynamicTileChunk(pix.data(), (int)(wr - pix.data()));
+    {
+        fflush(ctx->outFile);
+        const long all = ftell(ctx->outFile);
+        std::vector<u8> file((size_t)all);
+        fseek(ctx->outFile, 0, SEEK_SET);
+        if (all && fread(file.data(), 1, file.size(), ctx->outFile) != file.size()) return 2;
+        blob("chunks_file", file.data(), file.size());
+        fclose(ctx->outFile); ctx->outFile = nullptr;
+    }
+    if (argc > 4) {
+        // encode to a .yaik stream, then decode it back like an application would
+        FILE* yf = fopen(argv[4], "wb+"); if (!yf) return 2;
+        if (!ctx->ConvertHotPath(yf)) { fprintf(stderr, "ConvertHotPath: %s\n", ctx->LastError()); return 4; }
+        fflush(yf);
+        const long n = ftell(yf);
+        std::vector<u32> stream(((size_t)n + 3) / 4);                // 4-byte aligned, as YAIK.h requires
+        fseek(yf, 0, SEEK_SET);
+        if (fread(stream.data(), 1, (size_t)n, yf) != (size_t)n) return 2;
+        fclose(yf);
+        YAIK_LIB lib = YAIK_Init(1, nullptr);
+        if (!lib) { fprintf(stderr, "YAIK_Init failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        YAIK_SDecodedImage di;
+        if (!YAIK_DecodeImagePre(lib, stream.data(), (u32)n, &di)) { fprintf(stderr, "Pre failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        const int bpp = di.hasAlpha ? 4 : 3;
+        std::vector<u8> outImg((size_t)di.width * di.height * bpp);
+        di.outputImage = outImg.data(); di.outputImageStride = di.width * bpp;
+        if (!YAIK_DecodeImage(stream.data(), (u32)n, &di)) { fprintf(stderr, "Decode failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        int dims[3] = { di.width, di.height, bpp };
+        blob("yaik_dims", dims, sizeof dims);
+        blob("yaik_image", outImg.data(), outImg.size());
+        // second decode with a custom image builder: receives the 8x8-tiled planes
+        static std::vector<u8> tiled;
+        if (!YAIK_DecodeImagePre(lib, stream.data(), (u32)n, &di)) return 5;
+        di.outputImage = outImg.data(); di.outputImageStride = di.width * bpp;
+        di.customImageOutput = [](YAIK_SDecodedImage* u, YAIK_SCustomDataSource* s) {
+            const size_t planeSize = (size_t)(u->width / 8) * (u->height / 8) * 64;
+            tiled.assign(s->planeR, s->planeR + planeSize);
+            tiled.insert(tiled.end(), s->planeG, s->planeG + planeSize);
+            tiled.insert(tiled.end(), s->planeB, s->planeB + planeSize);
+        };
+        if (!YAIK_DecodeImage(stream.data(), (u32)n, &di)) { fprintf(stderr, "Decode (custom builder) failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        blob("yaik_planes_tiled", tiled.data(), tiled.size());
+        // error convention: a second Decode without Pre must fail with the sticky code, then read back as NO_ERROR
+        const bool again = YAIK_DecodeImage(stream.data(), (u32)n, &di);
+        int errs[3] = { again ? 1 : 0, (int)YAIK_GetErrorCode(), (int)YAIK_GetErrorCode() };
+        blob("yaik_error_convention", errs, sizeof errs);
+        YAIK_Release(lib);
+    }
     fclose(gOut);
     ctx->SetImageToEncode(nullptr);
     ctx->Release();
