@@ -73,21 +73,24 @@ def main() -> int:
 
     enc = HipTileEncoder(dev_index)
     enc.set_image(planes)
-    blob = torch.empty(enc.export_capacity(), dtype=torch.uint8, device=dev) if world > 1 else None
+    # N > 1: every rank encodes its own frame; the ONE collective of the path, the gather of the packed tile maps onto rank 0,
+    # is double-buffered so that the RCCL transfer of frame i rides under the encode kernels of frame i+1.
+    pipe = ykd.TileMapGatherPipeline(dist, comm_dev, enc.export_capacity(), dst=0, staging_device=dev) if world > 1 else None
 
     def step():
         enc.alpha_reject()
         enc.alpha_finish(None)
         enc.encode(3, args.mode3, False)
         if world > 1:
+            blob, _ = pipe.acquire()
             sizes = enc.export_tile_maps(blob)
-            payload = blob[: int(sizes[14])].cpu() if rehearsal else blob
-            ykd.gather_tile_maps(payload, int(sizes[14]), sizes, dist, dst=0)
+            pipe.submit(int(sizes[14]), sizes)
 
     def fence():
         torch.cuda.synchronize()
         enc.synchronize()
         if world > 1:
+            pipe.flush()                       # every gather has landed on rank 0 before the clock stops
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -84,6 +84,64 @@ def test_world2_gather_of_tile_maps(oracle_built):
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _pipe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cap = 1 << 16
+        pipe = ykd.TileMapGatherPipeline(dist, torch.device("cpu"), cap, dst=0)
+        # payload sizes per step: steady, then a jump beyond the 12.5 % headroom on rank 1 (forces the safe re-gather), then steady
+        sizes_per_step = [5000, 5100, 5050, 9000 if rank == 1 else 5000, 9000, 8000]
+        results = []
+
+        def payload(step, r, n):
+            return ((np.arange(n, dtype=np.int64) * (r + 3) + step * 7) & 255).astype(np.uint8)
+
+        def take(done):
+            if done is not None or rank != 0:                  # payload views are only valid until the buffer is acquired again
+                results.append(None if done is None else [(sz.copy(), pl.clone()) for sz, pl in done])
+        for step, n in enumerate(sizes_per_step):
+            buf, done = pipe.acquire()
+            if step >= 2:
+                take(done)
+            buf[:n] = torch.from_numpy(payload(step, rank, n))
+            sz = np.zeros(15, np.int64); sz[14] = n; sz[0] = step
+            pipe.submit(n, sz)
+        for done in pipe.flush():
+            take(done)
+        assert len(results) == len(sizes_per_step), len(results)
+        if rank == 0:
+            assert pipe.regathers == 2, pipe.regathers      # steps 3 and 4: the new length is only known when step 3 retires
+            for step, res in enumerate(results):
+                for r, (sz, pl) in enumerate(res):
+                    n = 9000 if (step == 3 and r == 1) else sizes_per_step[step]
+                    assert int(sz[14]) == n and int(sz[0]) == step, (step, r, sz)
+                    assert np.array_equal(pl.numpy(), payload(step, r, n)), (step, r)
+        else:
+            assert pipe.regathers == 2 and all(x is None for x in results)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_pipelined_gather_with_regather():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
 def test_pack_split_roundtrip():
     rng = np.random.default_rng(5)
     bitmaps = [rng.integers(0, 256, n, dtype=np.uint8) for n in (2, 4, 4, 8, 16, 16, 32)]

@@ -65,6 +65,106 @@ def gather_tile_maps(blob, nbytes: int, sizes: np.ndarray, dist, dst: int = 0):
     return None
 
 
+class TileMapGatherPipeline:
+    """Double-buffered, asynchronous form of gather_tile_maps for streams of frames / stripes.
+
+    The gather of step i (RCCL kernels on the communicator's stream, xGMI links) overlaps the encode kernels of step i+1.
+    Per step:  buf, done = pipe.acquire()   # waits for the gather that last used this buffer (two steps ago), returns its result
+               ... export the tile maps into buf ...
+               pipe.submit(nbytes, sizes)   # launches all_gather(sizes) + gather(payload) and returns immediately
+    and `pipe.flush()` at the end.  All ranks use one padded length per gather, derived from the sizes every rank reported in
+    an EARLIER step (+12.5 % headroom), so no rank waits for a size exchange before sending.  If some rank's payload outgrows
+    that length the step is re-gathered with the safe synchronous protocol when it is retired (every rank sees the same size
+    table, so all ranks take that branch together).  Results (on dst: list of (sizes[15], payload view) per rank; elsewhere
+    None) stay valid until the buffer they came from is acquired again.
+    """
+
+    def __init__(self, dist, device, capacity: int, dst: int = 0, headroom: float = 1.125, staging_device=None):
+        import torch
+        self.dist, self.dst, self.headroom = dist, dst, headroom
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.comm_device = device
+        # staging_device: where the encoder writes (HBM); differs from the communicator's device only in the gloo rehearsal
+        self.blobs = [torch.empty(capacity, dtype=torch.uint8, device=staging_device or device) for _ in range(2)]
+        self.send = [None, None]
+        self.meta = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(2)]
+        self.metas = [[torch.zeros(16, dtype=torch.int64, device=device) for _ in range(self.world)] for _ in range(2)]
+        self.recv = [None, None]
+        self.pad_used = [0, 0]
+        self.work = [None, None]
+        self.pad = 0
+        self.step = 0
+        self.regathers = 0
+
+    def _roundup(self, n: int) -> int:
+        return (int(n * self.headroom) + 4095) & ~4095
+
+    def acquire(self):
+        slot = self.step & 1
+        return self.blobs[slot], self._retire(slot)
+
+    def submit(self, nbytes: int, sizes) -> None:
+        import torch
+        slot = self.step & 1
+        assert self.work[slot] is None, "acquire() the buffer before exporting into it"
+        dist = self.dist
+        m = self.meta[slot]
+        m[0] = int(nbytes)
+        m[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=m.device)
+        if self.pad == 0:                                   # first step: agree on a length once, synchronously
+            dist.all_gather(self.metas[slot], m)
+            self.pad = self._roundup(int(torch.stack(self.metas[slot])[:, 0].max().item()))
+            w_meta = None
+        else:
+            w_meta = dist.all_gather(self.metas[slot], m, async_op=True)
+        pad = min(self.pad, self.blobs[slot].numel())
+        src = self.blobs[slot][:pad]
+        if src.device != self.comm_device:
+            src = src.to(self.comm_device)
+        self.send[slot] = src                               # keep alive until retired
+        if self.rank == self.dst:
+            if self.recv[slot] is None or self.recv[slot][0].numel() != pad:
+                self.recv[slot] = [torch.empty(pad, dtype=torch.uint8, device=self.comm_device) for _ in range(self.world)]
+            w = dist.gather(src, self.recv[slot], dst=self.dst, async_op=True)
+        else:
+            w = dist.gather(src, None, dst=self.dst, async_op=True)
+        self.work[slot] = (w_meta, w)
+        self.pad_used[slot] = pad
+        self.step += 1
+
+    def _retire(self, slot: int):
+        import torch
+        if self.work[slot] is None:
+            return None
+        w_meta, w = self.work[slot]
+        if w_meta is not None:
+            w_meta.wait()
+        w.wait()
+        self.work[slot] = None
+        metas = torch.stack(self.metas[slot]).cpu().numpy()
+        need = int(metas[:, 0].max())
+        pad = self.pad_used[slot]
+        self.pad = max(self.pad, self._roundup(need))
+        if need > pad:                                      # a payload was truncated: repeat this step with the safe protocol
+            self.regathers += 1
+            blob = self.blobs[slot]
+            if blob.device != self.comm_device:
+                blob = blob.to(self.comm_device)
+            return gather_tile_maps(blob, int(metas[self.rank, 0]), metas[self.rank, 1:16], self.dist, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        return [(metas[r, 1:16].copy(), self.recv[slot][r][: int(metas[r, 0])]) for r in range(self.world)]
+
+    def flush(self) -> list:
+        """Retire everything in flight, oldest first; returns their results in that order."""
+        out = []
+        for k in range(2):
+            slot = (self.step + k) & 1
+            if self.work[slot] is not None:
+                out.append(self._retire(slot))
+        return out
+
+
 def pack_blob(bitmaps, keep, defs, nibbles, n_nibbles) -> tuple[np.ndarray, np.ndarray]:
     """Host-side twin of yk_export_tile_maps' layout (sections padded to 16 bytes); returns (payload uint8, sizes[15])."""
     sizes = np.zeros(15, dtype=np.uint64)
