@@ -87,6 +87,14 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise YaikError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback for the product path)")
+        # PyTorch bundles its own HIP runtime; when both live in one process the bundled one must come up first (the
+        # reverse order leaves torch with "No HIP GPUs are available").  torch is only plumbing here, so this is best effort.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # noqa: BLE001
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -61,8 +61,11 @@ class HipTileEncoder:
             assert planes.dtype == torch.int32 and planes.is_cuda and planes.is_contiguous()
             base = planes.data_ptr()
             ptrs = (C.c_void_p * 4)(*[base + i * rows * w * 4 if i < n else None for i in range(4)])
-            stream = torch.cuda.current_stream(planes.device).cuda_stream
-            _chk(self._h, L.yk_set_stream(self._h, C.c_void_p(stream)))
+            # PyTorch ships its own copy of the HIP runtime; the library is linked against the system one.  Stream handles and
+            # the ordering of the two null streams do not carry across runtime instances (measured: a kernel launched here
+            # right after a torch kernel reads stale planes), so the hand-over is a host-side fence and the handle keeps its
+            # own stream.  Results handed back to torch are fenced the same way (every getter / export synchronises).
+            torch.cuda.current_stream(planes.device).synchronize()
             _chk(self._h, L.yk_bind_device_planes(self._h, ptrs, w))
         else:
             planes = np.ascontiguousarray(planes, dtype=np.int32)
