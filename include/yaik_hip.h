@@ -100,6 +100,13 @@ int    yk_coverage(yk_ctx* c, uint16_t* hostOut, size_t capElems);
 /* corner-colour stream of pass p = `rgbStream` (:4113-4132): CompressF(Round6(corner),250) bytes of every corner
  * not yet in `mappedRGB`, in scan order, de-duplicated across passes.  Call for p = 0..6 in order. */
 int    yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap, size_t* nBytes);
+/* Row stripes (new; SURVEY §8e "corner dedup across stripe-boundary lattice rows ... on the root"): a stripe handle
+ * de-duplicates inside its own rows, but its first and last lattice rows (y = y0 and y = y0 + h) are shared with the
+ * neighbouring stripes.  For those two rows, n = w/4 + 1 points each (first row, then last row): keys[i] = the stripe-local
+ * first-toucher key pass << 27 | bitIndex << 2 | corner (0xFFFFFFFF = untouched), index[i] = position, in corners, of that
+ * point's colour inside the stripe's stream of that pass.  The root drops the later of two emissions of one point:
+ * yaik_amd/distributed.py::merge_corner_streams.  capElems >= 2 * (w/4 + 1). */
+int    yk_gradient_corner_edges(yk_ctx* c, uint32_t* hostKeys, uint32_t* hostIndex, size_t capElems);
 
 /* range-quantiser results per plane (valid after yk_encode_tiles) ---------------------------------
  * tileDefs = `streamTileDef` u16 EncodeTileType(type,range,base) of tiles with >= 1 valid pixel, LeftRightOrder

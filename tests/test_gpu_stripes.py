@@ -17,7 +17,7 @@ def _encode_whole(planes, m3):
     a = e.mip_prefilter() if planes.shape[0] == 4 else None
     e.encode(3, m3, False)
     out = {"alpha": a, "bitmaps": [e.gradient_bitmap(i) for i in range(7)], "cov": e.coverage(),
-           "range": [e.range_streams(p) for p in range(3)]}
+           "range": [e.range_streams(p) for p in range(3)], "corners": [e.gradient_corners(i) for i in range(7)]}
     e.close()
     return out
 
@@ -43,6 +43,7 @@ def test_stripes_concatenate_to_whole_image(case, world):
     gb = ykd.combine_bboxes(boxes) if n == 4 else None
     bitmaps = [[] for _ in range(7)]
     covs, defs, nibs, nns = [], [[], [], []], [[], [], []], [[], [], []]
+    corner_streams, corner_edges = [], []
     abits, remaining = None, 0
     for e in encs:
         if e is None:
@@ -57,6 +58,8 @@ def test_stripes_concatenate_to_whole_image(case, world):
         for i in range(7):
             bitmaps[i].append(e.gradient_bitmap(i))
         covs.append(e.coverage())
+        corner_streams.append([e.gradient_corners(i) for i in range(7)])
+        corner_edges.append(e.gradient_corner_edges())
         for p in range(3):
             d, nb, nn = e.range_streams(p)
             defs[p].append(d); nibs[p].append(nb); nns[p].append(nn)
@@ -69,6 +72,10 @@ def test_stripes_concatenate_to_whole_image(case, world):
         assert np.array_equal(np.concatenate(defs[p]), wd)
         cat, total = ykd.concat_nibble_streams(nibs[p], nns[p])
         assert total == wnn and np.array_equal(cat, wn)
+    # corner-colour streams: stripe-local de-duplication + root-side reconciliation of the shared lattice rows
+    merged = ykd.merge_corner_streams(corner_streams, corner_edges)
+    for i in range(7):
+        assert np.array_equal(merged[i], whole["corners"][i]), f"corner stream {i}: {merged[i].size} vs {whole['corners'][i].size}"
     if n == 4:
         assert np.array_equal(abits, whole["alpha"]["bitmap"])
         assert remaining == whole["alpha"]["remaining"]

@@ -123,3 +123,34 @@ def test_stripe_partition_and_stream_concatenation():
     for i, v in enumerate(flat):
         want[i >> 1] |= v << ((i & 1) * 4)
     assert np.array_equal(out, want)
+
+
+def test_merge_corner_streams_drops_the_later_emission():
+    """Root-side reconciliation of the lattice row two stripes share: the copy of the later pass goes, stripe s+1's on a tie."""
+    from yaik_amd.distributed import merge_corner_streams
+    NONE = 0xFFFFFFFF
+    n = 5
+
+    def key(p, pos, corner):
+        return (p << 27) | (pos << 2) | corner
+    # stripe 0: pass 0 emits corners a0,a1 (a1 = boundary point x=1), pass 2 emits a2 (boundary x=3)
+    s0 = [np.array([10, 11, 12, 20, 21, 22], np.uint8)] + [np.zeros(0, np.uint8)] + [np.array([30, 31, 32], np.uint8)] + [np.zeros(0, np.uint8)] * 4
+    # stripe 1: pass 0 emits b0 (boundary x=3), pass 1 emits b1 (boundary x=1) and b2 (interior)
+    s1 = [np.array([40, 41, 42], np.uint8), np.array([50, 51, 52, 60, 61, 62], np.uint8)] + [np.zeros(0, np.uint8)] * 5
+    k0 = np.full((2, n), NONE, np.uint32); i0 = np.full((2, n), NONE, np.uint32)
+    k1 = np.full((2, n), NONE, np.uint32); i1 = np.full((2, n), NONE, np.uint32)
+    k0[1, 1], i0[1, 1] = key(0, 7, 2), 1          # stripe 0 last row, x=1: pass 0, second corner of its stream
+    k0[1, 3], i0[1, 3] = key(2, 5, 3), 0          # x=3: pass 2, first corner
+    k1[0, 1], i1[0, 1] = key(1, 0, 0), 0          # stripe 1 first row, x=1: pass 1 (later than stripe 0's pass 0 -> dropped)
+    k1[0, 3], i1[0, 3] = key(0, 2, 1), 0          # x=3: pass 0 (earlier than stripe 0's pass 2 -> stripe 0's copy dropped)
+    k1[0, 4], i1[0, 4] = key(0, 9, 0), 0          # only stripe 1 touches x=4: kept (index reused here on purpose: not consulted)
+    out = merge_corner_streams([s0, s1], [(k0, i0), (k1, i1)])
+    assert out[0].tolist() == [10, 11, 12, 20, 21, 22, 40, 41, 42]
+    assert out[1].tolist() == [60, 61, 62]
+    assert out[2].tolist() == []
+    # tie on the pass: the upper stripe's tiles come first in scan order
+    k1[0, 1] = key(0, 0, 0); i1[0, 1] = 0
+    s1b = [np.array([40, 41, 42, 70, 71, 72], np.uint8), np.array([60, 61, 62], np.uint8)] + [np.zeros(0, np.uint8)] * 5
+    i1[0, 3] = 0; i1[0, 1] = 1
+    out = merge_corner_streams([s0, s1b], [(k0, i0), (k1, i1)])
+    assert out[0].tolist() == [10, 11, 12, 20, 21, 22, 40, 41, 42] and out[1].tolist() == [60, 61, 62]

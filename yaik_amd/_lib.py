@@ -54,6 +54,7 @@ SIGNATURES = {
     "yk_gradient_counts": (C.c_int, [vp, vp]),
     "yk_coverage": (C.c_int, [vp, vp, sz]),
     "yk_gradient_corners": (C.c_int, [vp, C.c_int, vp, sz, szp]),
+    "yk_gradient_corner_edges": (C.c_int, [vp, vp, vp, sz]),
     "yk_range_sizes": (C.c_int, [vp, C.c_int, szp, szp]),
     "yk_range_streams": (C.c_int, [vp, C.c_int, vp, sz, vp, sz]),
     "yk_range_defs_device": (vp, [vp, C.c_int]),

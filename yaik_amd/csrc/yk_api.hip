@@ -20,7 +20,7 @@ static void yk_free_image(yk_ctx* c) {
     F(c->coverage); F(c->tileDef); F(c->tileCount); F(c->slots);
     for (int i = 0; i < 3; i++) F(c->dst[i]);
     F(c->blockSums); F(c->totals); F(c->defsOut); F(c->nibOut);
-    F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch);
+    F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
 }

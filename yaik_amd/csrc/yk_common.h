@@ -69,6 +69,7 @@ struct yk_ctx {
     uint32_t* latticeOwner = nullptr; size_t latticeElems = 0;
     uint8_t* cornerStream = nullptr; size_t cornerCap = 0;
     uint32_t* cornerScratch = nullptr; size_t cornerScratchElems = 0;
+    uint32_t* cornerEdgeIdx = nullptr;  // [2][w/4+1]: emission index (in corners, within its pass) of the first / last lattice row
     bool cornersReady = false; int nextCornerPass = 0;
     size_t cornerOff[7] = {}, cornerBytes[7] = {};
     // live 1-D range path (a15)

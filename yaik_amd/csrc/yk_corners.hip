@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ owner, uint32_t* __restrict__ wordCnt,
                                                                 const uint32_t* __restrict__ blockBase, const int32_t* const __restrict__ pR,
                                                                 const int32_t* const __restrict__ pG, const int32_t* const __restrict__ pB, int strideElems,
-                                                                uint8_t* __restrict__ out) {
+                                                                uint8_t* __restrict__ out, uint32_t* __restrict__ edgeIdx, int latH, int hAvail) {
     __shared__ uint32_t s_tmp[32];
     const size_t wi = (size_t)blockIdx.x * 1024 + threadIdx.x;
     const uint32_t word = wi < nWords ? bitmap[wi] : 0u;
@@ -89,7 +89,11 @@ __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* 
         for (int k = 0; k < 4; k++) {
             const int lx = (x >> 2) + ((k & 1) ? dx : 0), ly = (y >> 2) + ((k & 2) ? dy : 0);
             if (owner[(size_t)ly * latW + lx] == (key | (uint32_t)k)) {
-                const size_t src = (size_t)min(ly * 4, h - 1) * strideElems + min(lx * 4, w - 1);     // GetPixelValue clamp (:3853-3856)
+                // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
+                const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
+                // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
+                if (ly == 0) edgeIdx[lx] = off / 3u;
+                if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
                 const int v[3] = { pR[src], pG[src], pB[src] };
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* 
 }
 
 int yk_launch_corners(yk_ctx* c) {
-    if (c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "corner streams need a handle that owns the whole image (stripe lattice rows are shared)");
+    // Row stripes: the handle de-duplicates inside its own rows; its first and last lattice rows are shared with the
+    // neighbouring stripes and are reconciled on the root from yk_gradient_corner_edges (see distributed.merge_corner_streams).
     const int w = c->fullW, h = c->h;
     const int latW = w / 4 + 1, latH = h / 4 + 1;
     const size_t lat = (size_t)latW * latH;
@@ -113,6 +118,8 @@ int yk_launch_corners(yk_ctx* c) {
     const size_t nbMax = (maxWords + 1023) / 1024;
     if (!c->cornerScratch) { c->cornerScratchElems = maxWords + nbMax + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
     uint32_t* wordCnt = c->cornerScratch; uint32_t* blockBase = c->cornerScratch + maxWords; uint32_t* totalDev = blockBase + nbMax;
+    if (!c->cornerEdgeIdx) YK_HIP(c, hipMalloc(&c->cornerEdgeIdx, (size_t)latW * 2 * 4));
+    YK_HIP(c, hipMemsetAsync(c->cornerEdgeIdx, 0xFF, (size_t)latW * 2 * 4, c->stream));
     YK_HIP(c, hipMemsetAsync(c->latticeOwner, 0xFF, lat * 4, c->stream));
     for (int p = 0; p < 7; p++) {
         const size_t nWords = (c->bitmapBytes[p] + 3) / 4;      // bitmap allocations are padded by 16 bytes; pass 0 words may be half used
@@ -126,11 +133,13 @@ int yk_launch_corners(yk_ctx* c) {
         const unsigned nb = (unsigned)((nWords + 1023) / 1024);
         const uint32_t* bm = reinterpret_cast<const uint32_t*>(c->bitmap[p]);
         hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
-                           (const uint32_t*)nullptr, c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr);
+                           (const uint32_t*)nullptr, c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr, (uint32_t*)nullptr, latH,
+                           c->h + c->halo);
         hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3(nb), dim3(1024), 0, c->stream, wordCnt, nWords, blockBase);
         hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockBase, (int)nb, totalDev);
         hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
-                           blockBase, c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + off);
+                           blockBase, c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + off, c->cornerEdgeIdx, latH,
+                           c->h + c->halo);
         uint32_t total = 0;
         YK_HIP(c, hipMemcpyAsync(&total, totalDev, 4, hipMemcpyDeviceToHost, c->stream));
         YK_HIP(c, hipStreamSynchronize(c->stream));
@@ -156,5 +165,19 @@ extern "C" int yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t
             YK_HIP(c, hipStreamSynchronize(c->stream));
         }
     }
+    return YK_OK;
+}
+
+extern "C" int yk_gradient_corner_edges(yk_ctx* c, uint32_t* hostKeys, uint32_t* hostIndex, size_t capElems) {
+    if (!c || !hostKeys || !hostIndex) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
+    const size_t latW = (size_t)c->fullW / 4 + 1, latH = (size_t)c->h / 4 + 1;
+    if (capElems < 2 * latW) return yk_fail(c, YK_ERR_RANGE, "edge buffers need 2 * (w/4 + 1) elements");
+    YK_HIP(c, hipMemcpyAsync(hostKeys, c->latticeOwner, latW * 4, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipMemcpyAsync(hostKeys + latW, c->latticeOwner + (latH - 1) * latW, latW * 4, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipMemcpyAsync(hostIndex, c->cornerEdgeIdx, 2 * latW * 4, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
 }

@@ -212,6 +212,42 @@ def split_blob(sizes: np.ndarray, payload) -> dict:
     return out
 
 
+def merge_corner_streams(streams: list[list[np.ndarray]], edges: list[tuple[np.ndarray, np.ndarray]]) -> list[np.ndarray]:
+    """Image-wide corner-colour streams (`rgbStream` of the 7 gradient passes) from per-stripe streams.
+
+    streams[s][p] = stripe s's stream of pass p (3 bytes per corner, de-duplicated inside the stripe);
+    edges[s] = (keys[2, n], index[2, n]) from yk_gradient_corner_edges: first / last lattice row of stripe s.
+    A lattice point on the boundary between stripes s and s+1 may have been emitted by both.  The reference emits it once,
+    at its first toucher in (pass, scan order); tiles of stripe s precede those of stripe s+1 inside a pass, so the copy
+    of the later pass is dropped, and stripe s+1's copy on a tie.  Returns the 7 concatenated streams.
+    """
+    n_stripes = len(streams)
+    drop = [[[] for _ in range(7)] for _ in range(n_stripes)]
+    NONE = np.uint32(0xFFFFFFFF)
+    for s in range(n_stripes - 1):
+        ka, ia = edges[s][0][1], edges[s][1][1]             # last row of stripe s
+        kb, ib = edges[s + 1][0][0], edges[s + 1][1][0]     # first row of stripe s+1
+        both = (ka != NONE) & (kb != NONE)
+        pa, pb = (ka >> 27).astype(np.int64), (kb >> 27).astype(np.int64)
+        for x in np.nonzero(both)[0]:
+            if pa[x] <= pb[x]:
+                drop[s + 1][int(pb[x])].append(int(ib[x]))
+            else:
+                drop[s][int(pa[x])].append(int(ia[x]))
+    out = []
+    for p in range(7):
+        parts = []
+        for s in range(n_stripes):
+            st = np.asarray(streams[s][p], dtype=np.uint8).reshape(-1, 3)
+            if drop[s][p]:
+                keep = np.ones(st.shape[0], dtype=bool)
+                keep[np.asarray(drop[s][p], dtype=np.int64)] = False
+                st = st[keep]
+            parts.append(st.reshape(-1))
+        out.append(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+    return out
+
+
 def concat_nibble_streams(streams: list[np.ndarray], counts: list[int]) -> tuple[np.ndarray, int]:
     """Concatenate per-stripe nibble streams (low nibble first) into the image-wide stream of DynamicTileEncode."""
     total = int(sum(counts))

@@ -144,6 +144,13 @@ class HipTileEncoder:
         _chk(self._h, lib().yk_gradient_corners(self._h, p, out.ctypes.data, cap, C.byref(nb)))
         return out[:nb.value].copy()
 
+    def gradient_corner_edges(self):
+        """(keys[2, w/4+1], index[2, w/4+1]) of the stripe's first and last lattice rows (see yk_gradient_corner_edges)."""
+        n = self.w // 4 + 1
+        keys = np.zeros((2, n), dtype=np.uint32); idx = np.zeros((2, n), dtype=np.uint32)
+        _chk(self._h, lib().yk_gradient_corner_edges(self._h, keys.ctypes.data, idx.ctypes.data, 2 * n))
+        return keys, idx
+
     def range_streams(self, plane: int):
         L = lib()
         nd, nn = C.c_size_t(), C.c_size_t()
