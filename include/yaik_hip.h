@@ -158,7 +158,9 @@ int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, cons
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
- * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches */
+ * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches
+ * which = 1: floor((n + 0.5) * rcp(scale)) == n / scale for DiffRangeEncode's operands (EncoderContext.cpp:604-623)
+ * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391) */
 int yk_selftest(yk_ctx* c, int which, int* result);
 /* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
  * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums */

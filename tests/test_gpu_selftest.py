@@ -31,6 +31,13 @@ def test_reciprocal_scale_division_is_exact(hip):
     assert res.value == 0, f"{res.value} (scale, diff) pairs differ from the integer division of DiffRangeEncode"
 
 
+def test_reciprocal_model1_division_is_exact(hip):
+    from yaik_amd._lib import lib
+    res = C.c_int(-1)
+    assert lib().yk_selftest(hip._h, 2, C.byref(res)) == 0
+    assert res.value == 0, f"{res.value} (n, delta) pairs differ from the integer division of GetValueModel1"
+
+
 CORNER_CASES = {
     "synth256x4": lambda: synth_planes(256, n_planes=4), "synth512x3": lambda: synth_planes(512, n_planes=3),
     "mixed128": lambda: edge_image(128, 128, "mixed"), "ramp200x136": lambda: edge_image(200, 136, "ramp"),

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __r
     cntPix[i] = 16u * (4u - (uint32_t)__popc(q));
 }
 
+// One workgroup = 1024 consecutive tiles of one plane.  Phase 1: exclusive scans (thread = tile) give every tile its offset in
+// the type and pixel streams.  Phase 2: 16 lanes per tile, one lane per quadrant row (4 pixels): a 4-byte load from the pixel
+// stream, the 4 reconstructed bytes as one store into the 8x8-tiled plane — a wave writes 256 contiguous bytes.
 __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
                                                         const uint32_t* __restrict__ cntTiles, const uint32_t* __restrict__ cntPix,
                                                         const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
@@ -140,28 +143,50 @@ __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restric
                                                         const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
                                                         uint8_t* __restrict__ planes, size_t planeSize) {
     __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_offT[1024], s_offP[1024];
+    __shared__ uint8_t s_q[1024];
     const int p = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    uint32_t tot;
-    const uint32_t et = yk_block_exscan(i < T8 ? cntTiles[i] : 0u, s_tmp, &tot);
-    const uint32_t ep = yk_block_exscan(i < T8 ? cntPix[i] : 0u, s_tmp, &tot);
-    if (i >= T8 || !cntTiles[i]) return;
-    const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
-    int q = tile4[(tx >> 1) + (size_t)ty * stride4];
-    q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;
-    size_t to = ((size_t)p * totals[0] + baseTiles[blockIdx.x] + et) * 3, po = (size_t)p * totals[1] + basePix[blockIdx.x] + ep;
-    if (to + 2 >= typeBytes) return;
-    const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
-    const int delta2 = ((delta * invRange) >> 8) + 1;                           // :66, :86
-    uint8_t* tile = planes + (size_t)p * planeSize + i * 64;
-    for (int half = 0; half < 2; half++) {
-        const bool left = !(q & 1), right = !(q & 2);
-        q >>= 2;
-        for (int r = 0; r < 4; r++) for (int cx = 0; cx < 8; cx++) {
-            if ((cx < 4 && !left) || (cx >= 4 && !right)) continue;
-            const int L = po < pixBytes ? pix[po] : 0; po++;
-            tile[(half * 4 + r) * 8 + cx] = (uint8_t)(L ? (base + (((L - 1) * delta2) >> 16)) : color0);   // :113-124
+    const size_t i0 = (size_t)blockIdx.x * 1024;
+    {
+        const size_t i = i0 + threadIdx.x;
+        uint32_t tot;
+        const uint32_t et = yk_block_exscan(i < T8 ? cntTiles[i] : 0u, s_tmp, &tot);
+        const uint32_t ep = yk_block_exscan(i < T8 ? cntPix[i] : 0u, s_tmp, &tot);
+        int q = 0xF;
+        if (i < T8) {
+            const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
+            q = tile4[(tx >> 1) + (size_t)ty * stride4];
+            q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;                                // YAIK_3DTile.cpp:74-78: bit set = quadrant already filled
         }
+        s_offT[threadIdx.x] = baseTiles[blockIdx.x] + et; s_offP[threadIdx.x] = basePix[blockIdx.x] + ep; s_q[threadIdx.x] = (uint8_t)q;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, half = l16 >> 3, r = (l16 >> 1) & 3, side = l16 & 1;
+    for (int it = 0; it < 16; it++) {
+        const int t = it * 64 + (threadIdx.x >> 4);
+        const size_t i = i0 + t;
+        if (i >= T8) break;
+        const int q = s_q[t];
+        if (q == 0xF) continue;
+        const bool present = !((q >> (half * 2 + side)) & 1);
+        if (!present) continue;
+        const int nTop = 2 - (q & 1) - ((q >> 1) & 1), nBot = 2 - ((q >> 2) & 1) - ((q >> 3) & 1);
+        const bool leftPresent = !((q >> (half * 2)) & 1);
+        // stream order: half 0 rows (left then right quadrant of each row), then half 1 (:95-124)
+        const size_t po = (size_t)p * totals[1] + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)r * 4 * (half ? nBot : nTop) + ((side && leftPresent) ? 4 : 0);
+        const size_t to = ((size_t)p * totals[0] + s_offT[t]) * 3;
+        if (to + 2 >= typeBytes) continue;
+        const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
+        const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
+        const uint32_t L4 = (po + 3 < pixBytes) ? *reinterpret_cast<const uint32_t*>(pix + po) : 0u;      // po is a multiple of 4
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int L = (L4 >> (8 * k)) & 255;
+            const int v = L ? (base + (((L - 1) * delta2) >> 16)) : color0;     // :113-124
+            out |= (uint32_t)(v & 255) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(planes + (size_t)p * planeSize + i * 64 + (half * 4 + r) * 8 + side * 4) = out;
     }
 }
 
@@ -179,13 +204,32 @@ __global__ void yk_dec_mask_kernel(const uint8_t* __restrict__ bits, int bw, int
 // 3-byte-strided garbage; this kernel writes proper RGBA (4 B/pixel) instead, which is what YAIK.h documents.
 __global__ __launch_bounds__(256) void yk_dec_detile_kernel(const uint8_t* __restrict__ planes, size_t planeSize, int tileW, int w, int h,
                                                             const uint8_t* __restrict__ alpha, int strideA, uint8_t* __restrict__ out, size_t stride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    // one thread = 4 pixels of a row (half a tile row): one 4-byte load per plane, 12 (RGB) or 16 (RGBA) output bytes
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;                               // w is a multiple of 16
     const size_t ti = ((size_t)(y >> 3) * tileW + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7);
-    const int bpp = alpha ? 4 : 3;
-    uint8_t* o = out + (size_t)y * stride + (size_t)x * bpp;
-    o[0] = planes[ti]; o[1] = planes[planeSize + ti]; o[2] = planes[2 * planeSize + ti];
-    if (alpha) o[3] = alpha[(size_t)y * strideA + x];
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(planes + ti), g = *reinterpret_cast<const uint32_t*>(planes + planeSize + ti),
+                   b = *reinterpret_cast<const uint32_t*>(planes + 2 * planeSize + ti);
+    if (alpha) {
+        uint8_t* o = out + (size_t)y * stride + (size_t)x * 4;
+        const uint8_t* a = alpha + (size_t)y * strideA + x;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) px[k] = ((r >> (8 * k)) & 255u) | (((g >> (8 * k)) & 255u) << 8) | (((b >> (8 * k)) & 255u) << 16) | ((uint32_t)a[k] << 24);
+        if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) { uint32_t* o4 = reinterpret_cast<uint32_t*>(o); o4[0] = px[0]; o4[1] = px[1]; o4[2] = px[2]; o4[3] = px[3]; }
+        else for (int k = 0; k < 16; k++) o[k] = (uint8_t)(px[k >> 2] >> (8 * (k & 3)));
+    } else {
+        uint8_t* o = out + (size_t)y * stride + (size_t)x * 3;
+        const uint32_t r0 = r & 255u, r1 = (r >> 8) & 255u, r2 = (r >> 16) & 255u, r3 = r >> 24;
+        const uint32_t g0 = g & 255u, g1 = (g >> 8) & 255u, g2 = (g >> 16) & 255u, g3 = g >> 24;
+        const uint32_t b0 = b & 255u, b1 = (b >> 8) & 255u, b2 = (b >> 16) & 255u, b3 = b >> 24;
+        const uint32_t w0 = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24), w1 = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24), w2 = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
+        if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) { uint32_t* o4 = reinterpret_cast<uint32_t*>(o); o4[0] = w0; o4[1] = w1; o4[2] = w2; }
+        else {
+            const uint32_t ws[3] = { w0, w1, w2 };
+            for (int k = 0; k < 12; k++) o[k] = (uint8_t)(ws[k >> 2] >> (8 * (k & 3)));
+        }
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -325,7 +369,7 @@ int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, cons
     int rc = yk_dec_scratch(c, oA + aBytes + 64); if (rc) return rc;
     if (outputImageStride != (size_t)w * bpp) YK_HIP(c, hipMemsetAsync(c->dScratch, 0, outBytes, c->stream));   // row padding
     if (hostAlpha) YK_HIP(c, hipMemcpyAsync(c->dScratch + oA, hostAlpha, aBytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
+    hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
                        hostAlpha ? c->dScratch + oA : (const uint8_t*)nullptr, strideA, c->dScratch, outputImageStride);
     YK_HIP(c, hipGetLastError());
     YK_HIP(c, hipMemcpyAsync(hostOut, c->dScratch, outBytes, hipMemcpyDeviceToHost, c->stream));

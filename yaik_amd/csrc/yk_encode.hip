@@ -693,6 +693,16 @@ __global__ void yk_selftest_scale_kernel(int* mismatches) {
     if (ref != got) atomicAdd(mismatches, 1);
 }
 
+__global__ void yk_selftest_r1div_kernel(int* mismatches) {
+    const int n = blockIdx.x * 16 + (threadIdx.x >> 4), d0 = (threadIdx.x & 15) * 16;     // n 0..4095, d 1..255
+    for (int k = 0; k < 16; k++) {
+        const int d = d0 + k;
+        if (d < 1 || d > 255) continue;
+        const int got = __float2int_rz(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+        if (got != n / d) atomicAdd(mismatches, 1);
+    }
+}
+
 extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     if (!c || !result) return YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));
@@ -701,6 +711,7 @@ extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     YK_HIP(c, hipMemsetAsync(d, 0, sizeof(int), c->stream));
     if (which == 0) hipLaunchKernelGGL(yk_selftest_div_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else if (which == 1) hipLaunchKernelGGL(yk_selftest_scale_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 2) hipLaunchKernelGGL(yk_selftest_r1div_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
     YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));

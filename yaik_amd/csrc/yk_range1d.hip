@@ -10,85 +10,172 @@
 #include "yk_common.h"
 #include "yk_device.h"
 
-__global__ __launch_bounds__(256) void yk_range1d_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB,
-                                                         int strideElems, int w, int h, const uint16_t* __restrict__ coverage, int mtW,
-                                                         int tilesW, size_t T8, uint8_t* __restrict__ slots, uint8_t* __restrict__ params,
-                                                         uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t ti = (size_t)blockIdx.x * 4 + wave;
-    if (ti >= T8) return;
-    const int tx = (int)(ti % tilesW), ty = (int)(ti / tilesW);
-    const int x = lane & 7, y = lane >> 3;
-    const int gx = tx * 8 + x, gy = ty * 8 + y;
-    // quadrant coverage from the macro-tile coverage word (bit = cellY*4 + cellX)
-    const uint32_t cw = coverage[(size_t)(gy >> 4) * mtW + (gx >> 4)];
-    const int cellX0 = ((tx * 8) >> 2) & 3, cellY0 = ((ty * 8) >> 2) & 3;
-    const uint32_t cwT = coverage[(size_t)((ty * 8) >> 4) * mtW + ((tx * 8) >> 4)];
-    const bool u00 = !((cwT >> (cellY0 * 4 + cellX0)) & 1), u10 = !((cwT >> (cellY0 * 4 + cellX0 + 1)) & 1);
-    const bool u01 = !((cwT >> ((cellY0 + 1) * 4 + cellX0)) & 1), u11 = !((cwT >> ((cellY0 + 1) * 4 + cellX0 + 1)) & 1);
-    (void)cw;
-    const bool valid = (y < 4) ? ((x < 4) ? u00 : u10) : ((x < 4) ? u01 : u11);
+// (n + 0.5) * rcp(d) truncated == n / d for 0 <= n < 4096, 1 <= d <= 255 (exhaustive: yk_selftest 2)
+__device__ __forceinline__ int yk_r1_div(int n, int d) { return __float2int_rz(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
+
+// One wave64 per workgroup = a 64x16 strip = 16 tiles; a lane owns a 4x4 cell = one quadrant of an 8x8 tile, a tile is the four
+// lanes {l, l^1, l^4, l^5} (same geometry as yk_encode2_kernel).  Per plane: 256-byte row segments are loaded with 16-byte
+// loads and parked in LDS as bytes; the 256-bin histogram of a tile lives in 64 LDS words (4 byte-wide counters per word,
+// counts <= 64), filled with ds_add and read back per pixel; min / max / mode reductions are two xor-shuffles.
+__global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB,
+                                                        int strideElems, int w, int h, const uint16_t* __restrict__ coverage, int mtW,
+                                                        int tilesW, size_t T8, uint8_t* __restrict__ slots, uint8_t* __restrict__ params,
+                                                        uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_px[16 * 16];          // 16 rows x 64 pixels, one byte each
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[16 * 64];        // per tile: 256 byte-wide bins
+    const int lane = threadIdx.x;
+    const int xBB = (w + 63) >> 6;
+    const int BX = (int)(blockIdx.x % xBB), SY = (int)(blockIdx.x / xBB);    // strip coordinates (64 px, 16 rows)
+    const int q = lane >> 4, cell = lane & 15, cx = cell & 3, cy = cell >> 2;
+    const int gxCell = BX * 64 + q * 16 + cx * 4, gyCell = SY * 16 + cy * 4;
+    const bool mtIn = (BX * 64 + q * 16 < w) && (SY * 16 < h);
+    const uint32_t cw = mtIn ? coverage[(size_t)SY * mtW + (BX * 4 + q)] : 0xFFFFu;
+    const int cxl = cx & 1, cyl = cy & 1;
+    const int tgx = gxCell - cxl * 4, tgy = gyCell - cyl * 4;
+    const bool tileIn = (tgx + 8 <= w) && (tgy + 8 <= h);                    // the reference iterates whole 8x8 tiles (w, h multiples of 8)
+    const int c00 = (cy & 2) * 4 + (cx & 2);                                 // bit of the tile's top-left cell in the coverage word
+    const bool u00 = tileIn && !((cw >> c00) & 1), u10 = tileIn && !((cw >> (c00 + 1)) & 1);
+    const bool u01 = tileIn && !((cw >> (c00 + 4)) & 1), u11 = tileIn && !((cw >> (c00 + 5)) & 1);
+    const bool valid = cyl ? (cxl ? u11 : u01) : (cxl ? u10 : u00);          // this lane's quadrant is uncovered (:8420-8431)
     const int nTop = (int)u00 + (int)u10, nBot = (int)u01 + (int)u11;
     const int nPix = 16 * (nTop + nBot);
-    if (lane == 0) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
-    if (nPix == 0) return;                                     // wave-uniform
-    // position among the tile's emitted pixels: top half rows (left then right quadrant), then bottom half (:8420-8453)
-    const int pos = (y < 4) ? (y * 4 * nTop + ((x >= 4) ? 4 * (int)u00 : 0) + (x & 3))
-                            : (16 * nTop + (y - 4) * 4 * nBot + ((x >= 4) ? 4 * (int)u01 : 0) + (x & 3));
+    const size_t ti = (size_t)(tgy >> 3) * tilesW + (tgx >> 3);
+    const bool writer = tileIn && cxl == 0 && cyl == 0;
+    if (writer) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
+    if (__ballot(valid) == 0ULL) return;
+    const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the strip
+    uint32_t* hist = &s_hist[tw * 64];
+    // position of the lane's pixel rows among the tile's emitted pixels: top half rows (left then right quadrant), then bottom (:8420-8453)
+    const int posBase = cyl ? (16 * nTop + (cxl ? 4 * (int)u01 : 0)) : (cxl ? 4 * (int)u00 : 0);
+    const int posStep = 4 * (cyl ? nBot : nTop);
     const int32_t* planes[3] = { pR, pG, pB };
+    const int g4 = (lane & 15) * 4, r0 = lane >> 4;
     for (int p = 0; p < 3; p++) {
-        const int v = valid ? (planes[p][(size_t)gy * strideElems + gx] & 255) : -1;      // CompressF(v,255) == v
-        // histogram mode: count of equal valid values, right-most maximum wins (:8339-8344)
-        int cnt = 0;
-        for (int j = 0; j < 64; j++) {
-            const int vj = __shfl(v, j);
-            cnt += (vj == v) ? 1 : 0;
-        }
-        int key = valid ? ((cnt << 8) | v) : -1;
+        // ---- stage the strip of this plane as bytes -------------------------------------------------------------
+        {
+            const int gx = BX * 64 + g4;
+            uint32_t pk[4];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) key = max(key, __shfl_xor(key, d));
+            for (int k = 0; k < 4; k++) {
+                const int gy = SY * 16 + r0 + 4 * k;
+                int4 v = make_int4(0, 0, 0, 0);
+                if (gx + 3 < w && gy < h) v = *reinterpret_cast<const int4*>(planes[p] + (size_t)gy * strideElems + gx);
+                pk[k] = ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);   // CompressF(v,255) == v
+            }
+            __syncthreads();                                                 // previous plane's readers are done (single wave: LDS fence)
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_px[(r0 + 4 * k) * 16 + (lane & 15)] = pk[k];
+            *reinterpret_cast<uint4*>(&s_hist[lane * 16]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 8]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 12]) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+        uint32_t row[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) row[r] = s_px[(cy * 4 + r) * 16 + q * 4 + cx];
+        // ---- histogram of the tile's valid pixels, right-most mode (FindAndRemoveMostUsedColor, :8335-8356) --------
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t v = (row[k >> 2] >> (8 * (k & 3))) & 255u;
+                atomicAdd(&hist[v >> 2], 1u << (8 * (v & 3)));
+            }
+        }
+        __syncthreads();
+        int key = -1;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t v = (row[k >> 2] >> (8 * (k & 3))) & 255u;
+                const uint32_t cnt = (hist[v >> 2] >> (8 * (v & 3))) & 255u;
+                key = max(key, (int)((cnt << 8) | v));
+            }
+        }
+        key = max(key, __shfl_xor(key, 1)); key = max(key, __shfl_xor(key, 4));
         int color0 = key & 255;
         if (color0 == 0) color0 = 1;
         if (color0 == 255) color0 = 254;
-        const bool isC0 = valid && v >= color0 - 1 && v <= color0 + 1;
-        // Model1 over the remaining histogram (:8358-8381)
-        int mn = (valid && !isC0) ? v : 99999, mx = (valid && !isC0) ? v : -99999;
+        // ---- Model1 over what is left (:8358-8381) ------------------------------------------------------------------
+        int mn = 99999, mx = -99999;
+        if (valid) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { mn = min(mn, __shfl_xor(mn, d)); mx = max(mx, __shfl_xor(mx, d)); }
+            for (int k = 0; k < 16; k++) {
+                const int v = (int)((row[k >> 2] >> (8 * (k & 3))) & 255u);
+                const bool isC0 = (v >= color0 - 1) && (v <= color0 + 1);
+                mn = isC0 ? mn : min(mn, v); mx = isC0 ? mx : max(mx, v);
+            }
+        }
+        mn = min(mn, __shfl_xor(mn, 1)); mn = min(mn, __shfl_xor(mn, 4));
+        mx = max(mx, __shfl_xor(mx, 1)); mx = max(mx, __shfl_xor(mx, 4));
         int minCol = 0, delta = 0;
         if (mn != 99999) { minCol = mn; delta = mx - mn; }
         if (valid) {
-            int out = 0;
-            if (!isC0) {
-                const int idx = delta ? (((v - minCol) * 15) + ((delta >> 1) - 1)) / delta : 0;     // GetValueModel1 (:8383-8391)
-                out = 1 + idx;
+            uint8_t* slot = slots + ((size_t)p * T8 + ti) * 64;
+            const int round = (delta >> 1) - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t o4 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int v = (int)((row[r] >> (8 * i)) & 255u);
+                    int out = 0;
+                    if (!((v >= color0 - 1) && (v <= color0 + 1))) {
+                        int idx = 0;
+                        if (delta) {                                           // GetValueModel1 (:8383-8391), C division truncates toward zero
+                            const int n = (v - minCol) * 15 + round;
+                            idx = n < 0 ? -1 : yk_r1_div(n, delta);           // n < 0 only for delta == 1 (n = -1)
+                        }
+                        out = 1 + idx;
+                    }
+                    o4 |= ((uint32_t)out & 255u) << (8 * i);
+                }
+                *reinterpret_cast<uint32_t*>(slot + posBase + r * posStep) = o4;
             }
-            slots[((size_t)p * T8 + ti) * 64 + pos] = (uint8_t)out;
         }
-        if (lane == 0) {
-            uint8_t* q = params + ((size_t)p * T8 + ti) * 4;
-            q[0] = (uint8_t)color0; q[1] = (uint8_t)minCol; q[2] = (uint8_t)delta;
+        if (writer && nPix) {
+            uint8_t* qp = params + ((size_t)p * T8 + ti) * 4;
+            qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
         }
     }
 }
 
+// One workgroup = 1024 consecutive tiles of one plane: scans give every tile its stream offsets, then 16 lanes per tile copy
+// its pixel bytes as 4-byte words (offsets are multiples of 16) and one lane its three parameter bytes.
 __global__ __launch_bounds__(1024) void yk_range1d_pack_kernel(const uint32_t* __restrict__ cntTiles, const uint32_t* __restrict__ cntPix,
                                                                const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
                                                                const uint32_t* __restrict__ totals, size_t T8, const uint8_t* __restrict__ slots,
                                                                const uint8_t* __restrict__ params, uint8_t* __restrict__ pixOut, uint8_t* __restrict__ typeOut) {
     __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_offT[1024], s_offP[1024], s_n[1024];
     const int p = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    uint32_t tot;
-    const uint32_t et = yk_block_exscan(i < T8 ? cntTiles[i] : 0u, s_tmp, &tot);
-    const uint32_t ep = yk_block_exscan(i < T8 ? cntPix[i] : 0u, s_tmp, &tot);
-    if (i >= T8 || !cntTiles[i]) return;
-    const size_t to = ((size_t)p * totals[0] + baseTiles[blockIdx.x] + et) * 3, po = (size_t)p * totals[1] + basePix[blockIdx.x] + ep;
-    const uint8_t* q = params + ((size_t)p * T8 + i) * 4;
-    typeOut[to] = q[0]; typeOut[to + 1] = q[1]; typeOut[to + 2] = q[2];
-    const uint8_t* s = slots + ((size_t)p * T8 + i) * 64;
-    const uint32_t n = cntPix[i];
-    for (uint32_t k = 0; k < n; k++) pixOut[po + k] = s[k];
+    const size_t i0 = (size_t)blockIdx.x * 1024;
+    {
+        const size_t i = i0 + threadIdx.x;
+        uint32_t tot;
+        const uint32_t ct = i < T8 ? cntTiles[i] : 0u, cp = i < T8 ? cntPix[i] : 0u;
+        const uint32_t et = yk_block_exscan(ct, s_tmp, &tot);
+        const uint32_t ep = yk_block_exscan(cp, s_tmp, &tot);
+        s_offT[threadIdx.x] = baseTiles[blockIdx.x] + et; s_offP[threadIdx.x] = basePix[blockIdx.x] + ep; s_n[threadIdx.x] = cp;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    for (int it = 0; it < 16; it++) {
+        const int t = it * 64 + (threadIdx.x >> 4);
+        const size_t i = i0 + t;
+        if (i >= T8) break;
+        const uint32_t n = s_n[t];
+        if (!n) continue;
+        const size_t po = (size_t)p * totals[1] + s_offP[t];
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(slots + ((size_t)p * T8 + i) * 64);
+        uint32_t* o4 = reinterpret_cast<uint32_t*>(pixOut + po);
+        if ((uint32_t)l16 * 4 < n) o4[l16] = s4[l16];
+        if (l16 == 0) {
+            const size_t to = ((size_t)p * totals[0] + s_offT[t]) * 3;
+            const uint8_t* qp = params + ((size_t)p * T8 + i) * 4;
+            typeOut[to] = qp[0]; typeOut[to + 1] = qp[1]; typeOut[to + 2] = qp[2];
+        }
+    }
 }
 
 extern "C" {
@@ -106,7 +193,8 @@ int yk_range1d_encode(yk_ctx* c) {
         YK_HIP(c, hipMalloc(&c->r1Type, 3 * T8 * 3 + 64));
     }
     uint32_t* cT = c->r1Cnt; uint32_t* cP = cT + T8; uint32_t* bT = cP + T8; uint32_t* bP = bT + nb + 16; uint32_t* tot = bP + nb + 16;
-    hipLaunchKernelGGL(yk_range1d_kernel, dim3((unsigned)((T8 + 3) / 4)), dim3(256), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+    const unsigned nStrips = (unsigned)(((c->fullW + 63) / 64) * ((c->h + 15) / 16));
+    hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
                        c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP);
     hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
     hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
