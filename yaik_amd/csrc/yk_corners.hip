@@ -48,61 +48,49 @@ __global__ __launch_bounds__(256) void yk_corner_owner_kernel(const uint32_t* __
     }
 }
 
+// One thread per tile slot (bit) of the pass's bitmap, 1024 slots per workgroup.  COUNT: corners owned per workgroup.
+// EMIT: exclusive scan inside the workgroup + the scanned workgroup bases = byte offset of every owned corner.
 template <bool EMIT>
-__global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, int pass, int w, int h, int latW,
-                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ wordCnt,
-                                                                const uint32_t* __restrict__ blockBase, const int32_t* const __restrict__ pR,
-                                                                const int32_t* const __restrict__ pG, const int32_t* const __restrict__ pB, int strideElems,
+__global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, int pass, int w, int latW,
+                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums,
+                                                                const int32_t* const __restrict__ pR, const int32_t* const __restrict__ pG,
+                                                                const int32_t* const __restrict__ pB, int strideElems,
                                                                 uint8_t* __restrict__ out, uint32_t* __restrict__ edgeIdx, int latH, int hAvail) {
     __shared__ uint32_t s_tmp[32];
-    const size_t wi = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t word = wi < nWords ? bitmap[wi] : 0u;
+    const size_t pos = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool set = pos < nBits && ((bitmap[pos >> 5] >> (pos & 31)) & 1u);
     const PassGeo g = yk_pass_geo(pass, w);
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    uint32_t cnt = 0;
-    if (!EMIT) {
-        uint32_t bits = word;
-        while (bits) {
-            const int b = __ffs(bits) - 1; bits &= bits - 1;
-            const uint32_t pos = (uint32_t)(wi * 32 + b);
-            int x, y; yk_tile_from_bit(g, pos, x, y);
-            const int lx = x >> 2, ly = y >> 2;
-            const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
-            cnt += owner[(size_t)ly * latW + lx] == (key | 0u);
-            cnt += owner[(size_t)ly * latW + lx + dx] == (key | 1u);
-            cnt += owner[(size_t)(ly + dy) * latW + lx] == (key | 2u);
-            cnt += owner[(size_t)(ly + dy) * latW + lx + dx] == (key | 3u);
-        }
-        if (wi < nWords) wordCnt[wi] = cnt;
-        return;
+    int x = 0, y = 0;
+    uint32_t own = 0, cnt = 0;
+    const uint32_t key = ((uint32_t)pass << 27) | ((uint32_t)pos << 2);
+    if (set) {
+        yk_tile_from_bit(g, (uint32_t)pos, x, y);
+        const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
+        own = (owner[l0] == (key | 0u) ? 1u : 0u) | (owner[l0 + dx] == (key | 1u) ? 2u : 0u) |
+              (owner[l0 + (size_t)dy * latW] == (key | 2u) ? 4u : 0u) | (owner[l0 + (size_t)dy * latW + dx] == (key | 3u) ? 8u : 0u);
+        cnt = (uint32_t)__popc(own);
     }
-    cnt = wi < nWords ? wordCnt[wi] : 0u;
     uint32_t tot;
-    uint32_t off = (blockBase[blockIdx.x] + yk_block_exscan(cnt, s_tmp, &tot)) * 3u;
-    uint32_t bits = word;
-    while (bits) {
-        const int b = __ffs(bits) - 1; bits &= bits - 1;
-        const uint32_t pos = (uint32_t)(wi * 32 + b);
-        int x, y; yk_tile_from_bit(g, pos, x, y);
-        const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
+    const uint32_t ex = yk_block_exscan(cnt, s_tmp, &tot);
+    if (!EMIT) { if (threadIdx.x == 0) blockSums[blockIdx.x] = tot; return; }
+    uint32_t off = (blockSums[blockIdx.x] + ex) * 3u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int lx = (x >> 2) + ((k & 1) ? dx : 0), ly = (y >> 2) + ((k & 2) ? dy : 0);
-            if (owner[(size_t)ly * latW + lx] == (key | (uint32_t)k)) {
-                // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
-                const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
-                // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
-                if (ly == 0) edgeIdx[lx] = off / 3u;
-                if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
-                const int v[3] = { pR[src], pG[src], pB[src] };
+    for (int k = 0; k < 4; k++) {
+        if (!((own >> k) & 1u)) continue;
+        const int lx = (x >> 2) + ((k & 1) ? dx : 0), ly = (y >> 2) + ((k & 2) ? dy : 0);
+        // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
+        const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
+        // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
+        if (ly == 0) edgeIdx[lx] = off / 3u;
+        if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
+        const int v[3] = { pR[src], pG[src], pB[src] };
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
-                    out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
-                }
-                off += 3;
-            }
+        for (int ch = 0; ch < 3; ch++) {
+            const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
+            out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
         }
+        off += 3;
     }
 }
 
@@ -113,11 +101,14 @@ int yk_launch_corners(yk_ctx* c) {
     const int latW = w / 4 + 1, latH = h / 4 + 1;
     const size_t lat = (size_t)latW * latH;
     if (!c->latticeOwner) { YK_HIP(c, hipMalloc(&c->latticeOwner, lat * 4)); c->latticeElems = lat; }
-    if (!c->cornerStream) { c->cornerCap = lat * 3 + 64; YK_HIP(c, hipMalloc(&c->cornerStream, c->cornerCap)); }
-    const size_t maxWords = (c->bitmapBytes[6] + 3) / 4 + 1;
-    const size_t nbMax = (maxWords + 1023) / 1024;
-    if (!c->cornerScratch) { c->cornerScratchElems = maxWords + nbMax + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
-    uint32_t* wordCnt = c->cornerScratch; uint32_t* blockBase = c->cornerScratch + maxWords; uint32_t* totalDev = blockBase + nbMax;
+    // every lattice point is emitted at most once over the seven passes, so one buffer of lat*3 bytes holds all streams back to
+    // back; the passes are laid out at their worst-case offsets (pass p after everything passes < p could emit) = 7 regions
+    const size_t region = lat * 3 + 16;
+    if (!c->cornerStream) { c->cornerCap = region * 7; YK_HIP(c, hipMalloc(&c->cornerStream, c->cornerCap)); }
+    size_t nbTot = 0; size_t nbOf[7], bitsOf[7];
+    for (int p = 0; p < 7; p++) { bitsOf[p] = c->bitmapBytes[p] * 8; nbOf[p] = (bitsOf[p] + 1023) / 1024; nbTot += nbOf[p]; }
+    if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
+    uint32_t* totalDev = c->cornerScratch + nbTot;
     if (!c->cornerEdgeIdx) YK_HIP(c, hipMalloc(&c->cornerEdgeIdx, (size_t)latW * 2 * 4));
     YK_HIP(c, hipMemsetAsync(c->cornerEdgeIdx, 0xFF, (size_t)latW * 2 * 4, c->stream));
     YK_HIP(c, hipMemsetAsync(c->latticeOwner, 0xFF, lat * 4, c->stream));
@@ -127,27 +118,22 @@ int yk_launch_corners(yk_ctx* c) {
         hipLaunchKernelGGL(yk_corner_owner_kernel, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, c->stream,
                            reinterpret_cast<const uint32_t*>(c->bitmap[p]), nWords, p, w, latW, c->latticeOwner);
     }
-    size_t off = 0;
+    uint32_t* blockSums = c->cornerScratch;
     for (int p = 0; p < 7; p++) {
-        const size_t nWords = (c->bitmapBytes[p] + 3) / 4;
-        const unsigned nb = (unsigned)((nWords + 1023) / 1024);
+        const unsigned nb = (unsigned)nbOf[p];
         const uint32_t* bm = reinterpret_cast<const uint32_t*>(c->bitmap[p]);
-        hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
-                           (const uint32_t*)nullptr, c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr, (uint32_t*)nullptr, latH,
-                           c->h + c->halo);
-        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3(nb), dim3(1024), 0, c->stream, wordCnt, nWords, blockBase);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockBase, (int)nb, totalDev);
-        hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3(nb), dim3(1024), 0, c->stream, bm, nWords, p, w, h, latW, c->latticeOwner, wordCnt,
-                           blockBase, c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + off, c->cornerEdgeIdx, latH,
-                           c->h + c->halo);
-        uint32_t total = 0;
-        YK_HIP(c, hipMemcpyAsync(&total, totalDev, 4, hipMemcpyDeviceToHost, c->stream));
-        YK_HIP(c, hipStreamSynchronize(c->stream));
-        c->cornerOff[p] = off; c->cornerBytes[p] = (size_t)total * 3;
-        off += (size_t)total * 3;
-        if (off > c->cornerCap) return yk_fail(c, YK_ERR_RANGE, "corner stream overflow");
+        hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3(nb), dim3(1024), 0, c->stream, bm, bitsOf[p], p, w, latW, c->latticeOwner, blockSums,
+                           c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr, (uint32_t*)nullptr, latH, c->h + c->halo);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, (int)nb, totalDev + p);
+        hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3(nb), dim3(1024), 0, c->stream, bm, bitsOf[p], p, w, latW, c->latticeOwner, blockSums,
+                           c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + region * p, c->cornerEdgeIdx, latH, c->h + c->halo);
+        blockSums += nb;
     }
     YK_HIP(c, hipGetLastError());
+    uint32_t totals[7];
+    YK_HIP(c, hipMemcpyAsync(totals, totalDev, sizeof totals, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < 7; p++) { c->cornerOff[p] = region * p; c->cornerBytes[p] = (size_t)totals[p] * 3; }
     c->cornersReady = true;
     return YK_OK;
 }
