@@ -169,7 +169,10 @@ int yk_set_ablation(yk_ctx* c, int flags);
  * Both produce identical results; kept selectable for A/B timing and as a cross-check in the tests. */
 int yk_set_kernel_version(yk_ctx* c, int version);
 
-/* ---- timing hooks for bench.py: HIP events on the handle's stream around the last yk_encode_tiles ---- */
+/* ---- timing hooks for bench.py: HIP events on the handle's stream around every alpha stage / fused kernel / compaction.
+ * Returns the averages over the yk_encode_tiles calls since the previous query (a ring of 64 event sets, older ones are
+ * dropped), so a caller can queue many frames back to back and read the per-kernel times once, without a sync per frame.
+ * Synchronises with the most recent encode. */
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);
 
 #ifdef __cplusplus

@@ -45,7 +45,7 @@ int yk_create(int device, yk_ctx** out) {
     if (hipDeviceGetAttribute(&c->numCU, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->numCU <= 0) c->numCU = 256;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return YK_ERR_HIP; }
     c->stream = c->ownStream;
-    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
+    for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (hipEventCreate(&c->evRing[r][i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
     *out = c;
     return YK_OK;
 }
@@ -57,7 +57,7 @@ void yk_destroy(yk_ctx* c) {
     yk_free_image(c);
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
-    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -94,7 +94,7 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
     c->fullW = fullW; c->fullH = fullH; c->nPlanes = nPlanes; c->y0 = y0; c->h = h; c->halo = haloRows;
     c->tilesW = fullW / 8; c->tilesH = h / 8; c->mtW = (fullW + 15) / 16; c->mtH = (h + 15) / 16;
     const size_t T8 = (size_t)c->tilesW * c->tilesH, MT = (size_t)c->mtW * c->mtH;
-    YK_HIP(c, hipMalloc(&c->keep, MT));
+    YK_HIP(c, hipMalloc(&c->keep, MT + 16));             // read as 4-byte words by yk_alpha_bbox_kernel
     YK_HIP(c, hipMalloc(&c->bounds, 16 * sizeof(int32_t)));
     static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
     for (int i = 0; i < 7; i++) {
@@ -161,9 +161,11 @@ int yk_alpha_reject(yk_ctx* c) {
     if (!c->plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
     if (c->nPlanes != 4) return yk_fail(c, YK_ERR_STATE, "image has no alpha plane");
     YK_HIP(c, hipSetDevice(c->device));
-    YK_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];
+    YK_HIP(c, hipEventRecord(ev[0], c->stream));
     int rc = yk_launch_alpha(c); if (rc) return rc;
-    YK_HIP(c, hipEventRecord(c->ev[1], c->stream));
+    YK_HIP(c, hipEventRecord(ev[1], c->stream));
+    c->evAlphaInCur = true;
     c->alphaDone = true; c->alphaFinished = false;
     return YK_OK;
 }
@@ -267,11 +269,16 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
             }
         }
     }
-    YK_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];
+    if (!c->evAlphaInCur) { YK_HIP(c, hipEventRecord(ev[0], c->stream)); YK_HIP(c, hipEventRecord(ev[1], c->stream)); }   // no alpha stage: zero-length interval
+    YK_HIP(c, hipEventRecord(ev[2], c->stream));
     int rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, wantDst); if (rc) return rc;
-    YK_HIP(c, hipEventRecord(c->ev[3], c->stream));
+    YK_HIP(c, hipEventRecord(ev[3], c->stream));
     rc = yk_launch_pack(c); if (rc) return rc;
-    YK_HIP(c, hipEventRecord(c->ev[4], c->stream));
+    YK_HIP(c, hipEventRecord(ev[4], c->stream));
+    c->evAlphaInCur = false;
+    c->evHead++;
+    if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;       // the oldest sets were overwritten
     c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
@@ -396,16 +403,22 @@ int yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15])
 
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs) {
     if (!c) return YK_ERR_BAD_ARG;
-    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    if (!c->encoded || c->evHead == c->evTail) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
     YK_HIP(c, hipSetDevice(c->device));
-    YK_HIP(c, hipEventSynchronize(c->ev[4]));
-    float a = 0, e = 0, p = 0;
-    if (c->nPlanes == 4 && c->alphaDone) YK_HIP(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-    YK_HIP(c, hipEventElapsedTime(&e, c->ev[2], c->ev[3]));
-    YK_HIP(c, hipEventElapsedTime(&p, c->ev[3], c->ev[4]));
-    if (fusedEncodeMs) *fusedEncodeMs = e;
-    if (alphaMs) *alphaMs = a;
-    if (packMs) *packMs = p;
+    YK_HIP(c, hipEventSynchronize(c->evRing[(c->evHead - 1) % YK_EV_RING][4]));
+    double a = 0, e = 0, p = 0;
+    const unsigned n = c->evHead - c->evTail;
+    for (unsigned k = c->evTail; k != c->evHead; k++) {                         // average over the encodes since the last query
+        hipEvent_t* ev = c->evRing[k % YK_EV_RING];
+        float t = 0;
+        YK_HIP(c, hipEventElapsedTime(&t, ev[0], ev[1])); a += t;
+        YK_HIP(c, hipEventElapsedTime(&t, ev[2], ev[3])); e += t;
+        YK_HIP(c, hipEventElapsedTime(&t, ev[3], ev[4])); p += t;
+    }
+    c->evTail = c->evHead;
+    if (fusedEncodeMs) *fusedEncodeMs = (float)(e / n);
+    if (alphaMs) *alphaMs = (float)(a / n);
+    if (packMs) *packMs = (float)(p / n);
     return YK_OK;
 }
 

@@ -9,6 +9,7 @@
 #define YK_BLK      64      // pixels per workgroup block side (= the 64x64 swizzle block of include/YAIK_private.h:212)
 #define YK_LSTRIDE  68      // LDS row pitch in 32-bit words (65 used, 16-byte aligned rows)
 #define YK_LROWS    65
+#define YK_EV_RING  64
 #define YK_SLOT     32      // bytes of nibble slot per 8x8 tile-plane (64 nibbles)
 
 struct YkEncodeParams {
@@ -82,7 +83,11 @@ struct yk_ctx {
     uint8_t* dLoaded = nullptr;         // lattice point already popped from a colour stream (mapRGBMask)
     bool dSplit = false;
     // timing
-    hipEvent_t ev[6] = {};
+    // timing events: a ring of YK_EV_RING sets {alpha begin, alpha end, encode begin, encode end, pack end} so that a caller can
+    // run many frames back to back and read the per-kernel averages afterwards without synchronising every frame
+    hipEvent_t evRing[YK_EV_RING][5] = {};
+    unsigned evHead = 0, evTail = 0;      // sets [evTail, evHead) hold a completed encode; evCur = evHead % YK_EV_RING is being filled
+    bool evAlphaInCur = false;
     float msEncode = 0, msAlpha = 0, msPack = 0;
     int ablate = 0;
     int kernelVersion = 2;              // 1 = yk_encode_kernel (lane = pixel row), 2 = yk_encode2_kernel (lane = 4x4 cell)

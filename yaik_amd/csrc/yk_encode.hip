@@ -28,7 +28,9 @@ __constant__ float c_curve[6][16] = YK_CURVE_TABLE;
 // streaming path has no atomics.  The bounding box is derived from the flags afterwards (yk_alpha_bbox_kernel).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h,
-                                                       uint8_t* __restrict__ keep, int mtW) {
+                                                       uint8_t* __restrict__ keep, int mtW, int32_t* __restrict__ bounds) {
+    // accumulators of the bounding-box kernel that follows on the stream: {x0,y0,x1,y1} = empty, done-counter = 0
+    if (blockIdx.x == 0 && threadIdx.x < 5) bounds[8 + threadIdx.x] = threadIdx.x < 2 ? 9999999 : (threadIdx.x < 4 ? -1 : 0);
     const int lane = threadIdx.x & 63;
     const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
     const int nSeg = (vecPerRow + 1023) >> 10;
@@ -53,16 +55,26 @@ __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict
 }
 
 // bounding box of the kept 16x16 tiles (quadRecursion's boundingL/T/R/B, EncoderContext.cpp:416-422) from the keep flags;
-// one guarded atomic per workgroup and bound (a single address only sustains ~88 atomics/us).
-__global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint8_t* __restrict__ keep, int mtW, int mtH, int y0, int32_t* __restrict__ bbox) {
+// one atomic per workgroup and bound (a single address only sustains ~88 atomics/us).  The last workgroup to finish also
+// publishes the whole-image form: bounds[0..3] = the box, bounds[4] = "bbox == whole image -> every reject discarded"
+// (EncoderContext.cpp:1294, :1400-1403); a stripe caller overrides these five ints with the host-combined box.
+__global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint32_t* __restrict__ keep4, int mtW, int mtH, int y0, int32_t* __restrict__ bounds,
+                                                            int fullW, int fullH) {
     __shared__ int s_red[4][4];
+    int32_t* bbox = bounds + 8;
     int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
-    const int n = mtW * mtH;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (keep[i]) {
-            const int my = i / mtW, mx = i - my * mtW;
-            x0 = min(x0, mx * 16); x1 = max(x1, mx * 16 + 16);
-            gy0 = min(gy0, y0 + my * 16); gy1 = max(gy1, y0 + my * 16 + 16);
+    const int n = mtW * mtH, n4 = (n + 3) >> 2;                  // four 1-byte flags per load (the map is padded to a multiple of 4)
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+        uint32_t f = keep4[i4];
+        if (!f) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i4 * 4 + k;
+            if (((f >> (8 * k)) & 255u) && i < n) {
+                const int my = i / mtW, mx = i - my * mtW;
+                x0 = min(x0, mx * 16); x1 = max(x1, mx * 16 + 16);
+                gy0 = min(gy0, y0 + my * 16); gy1 = max(gy1, y0 + my * 16 + 16);
+            }
         }
     }
 #pragma unroll
@@ -78,16 +90,12 @@ __global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint8_t* __res
             x0 = min(x0, s_red[k][0]); gy0 = min(gy0, s_red[k][1]); x1 = max(x1, s_red[k][2]); gy1 = max(gy1, s_red[k][3]);
         }
         if (x1 >= 0) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], gy0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], gy1); }
-    }
-}
-
-// stage 2 when the caller does not supply an image-wide bbox: the handle's own accumulators are the whole image.
-// "bbox == whole image -> every reject discarded" (EncoderContext.cpp:1294, :1400-1403).
-__global__ void yk_alpha_finish_kernel(int32_t* bounds, int fullW, int fullH) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int x0 = bounds[8], y0 = bounds[9], x1 = bounds[10], y1 = bounds[11];
-        bounds[0] = x0; bounds[1] = y0; bounds[2] = x1; bounds[3] = y1;
-        bounds[4] = (x0 == 0 && y0 == 0 && x1 == fullW && y1 == fullH) ? 1 : 0;
+        __threadfence();
+        if (atomicAdd(&bbox[4], 1) == (int)gridDim.x - 1) {       // every other workgroup's atomics are visible now
+            const int bx0 = atomicAdd(&bbox[0], 0), by0 = atomicAdd(&bbox[1], 0), bx1 = atomicAdd(&bbox[2], 0), by1 = atomicAdd(&bbox[3], 0);
+            bounds[0] = bx0; bounds[1] = by0; bounds[2] = bx1; bounds[3] = by1;
+            bounds[4] = (bx0 == 0 && by0 == 0 && bx1 == fullW && by1 == fullH) ? 1 : 0;
+        }
     }
 }
 
@@ -616,27 +624,25 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 int yk_launch_alpha(yk_ctx* c) {
-    static const int32_t init[16] = { 0, 0, 0, 0, 1, 0, 0, 0, 9999999, 9999999, -1, -1, 0, 0, 0, 0 };
-    YK_HIP(c, hipMemcpyAsync(c->bounds, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    YK_HIP(c, hipMemsetAsync(c->keep, 0, (size_t)c->mtW * c->mtH, c->stream));
+    const size_t nFlags = ((size_t)c->mtW * c->mtH + 3) & ~(size_t)3;
+    YK_HIP(c, hipMemsetAsync(c->keep, 0, nFlags, c->stream));
     const int nUnits = ((c->fullW / 4 + 1023) / 1024) * c->h;
     hipLaunchKernelGGL(yk_alpha_kernel, dim3(nUnits < 4096 ? nUnits : 4096), dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h,
-                       c->keep, c->mtW);
+                       c->keep, c->mtW, c->bounds);
     YK_HIP(c, hipGetLastError());
-    const int nb = (c->mtW * c->mtH + 4095) / 4096;
-    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, c->stream, c->keep, c->mtW, c->mtH, c->y0, c->bounds + 8);
+    const int nb = (int)((nFlags / 4 + 1023) / 1024);
+    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 128 ? nb : 128), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->keep), c->mtW, c->mtH,
+                       c->y0, c->bounds, c->fullW, c->fullH);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
 
 int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox) {
+    // whole image: yk_alpha_bbox_kernel already published bounds[0..4]; stripes: the host-combined box replaces them
     if (globalBBox) {
         int32_t b[5] = { globalBBox[0], globalBBox[1], globalBBox[2], globalBBox[3], 0 };
         b[4] = (b[0] == 0 && b[1] == 0 && b[2] == c->fullW && b[3] == c->fullH) ? 1 : 0;
         YK_HIP(c, hipMemcpyAsync(c->bounds, b, sizeof b, hipMemcpyHostToDevice, c->stream));
-    } else {
-        hipLaunchKernelGGL(yk_alpha_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->bounds, c->fullW, c->fullH);
-        YK_HIP(c, hipGetLastError());
     }
     return YK_OK;
 }
