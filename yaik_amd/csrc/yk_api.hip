@@ -19,7 +19,7 @@ static void yk_free_image(yk_ctx* c) {
     for (int i = 0; i < 7; i++) F(c->bitmap[i]);
     F(c->coverage); F(c->tileDef); F(c->tileCount); F(c->slots);
     for (int i = 0; i < 3; i++) F(c->dst[i]);
-    F(c->blockSums); F(c->totals); F(c->defsOut); F(c->nibOut);
+    F(c->blockSums); F(c->blockCnt); F(c->totals); F(c->defsOut); F(c->nibOut);
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
@@ -108,7 +108,9 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
     YK_HIP(c, hipMalloc(&c->tileCount, 3 * T8));
     YK_HIP(c, hipMalloc(&c->slots, 3 * T8 * YK_SLOT));
     c->nScanBlocks = (int)((T8 + 1023) / 1024);
-    YK_HIP(c, hipMalloc(&c->blockSums, (size_t)3 * c->nScanBlocks * 2 * sizeof(uint32_t)));
+    YK_HIP(c, hipMalloc(&c->blockSums, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t)));
+    YK_HIP(c, hipMalloc(&c->blockCnt, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t)));
+    YK_HIP(c, hipMemsetAsync(c->blockCnt, 0, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t), c->stream));   // kept zero between frames by the scan
     YK_HIP(c, hipMalloc(&c->totals, 6 * sizeof(uint32_t)));
     YK_HIP(c, hipMalloc(&c->defsOut, 3 * T8 * sizeof(uint16_t)));
     c->nibStride = T8 * YK_SLOT + 64;

@@ -30,6 +30,7 @@ struct YkEncodeParams {
     uint16_t* tileDef;      // [3][tilesW*tilesH]
     uint8_t*  tileCount;    // [3][tilesW*tilesH]
     uint8_t*  slots;        // [3][tilesW*tilesH][32]
+    uint32_t* blockCnt;     // [ceil(tiles/1024)][2]: nibbles and coded tiles per scan block (atomics; nullptr = the scan counts itself)
     int32_t*  dst[3];
     int tilesW, tilesH, mtW, mtH;
     int xBB64, yBB64, xBB32, yBB32;
@@ -59,7 +60,8 @@ struct yk_ctx {
     uint16_t* tileDef = nullptr; uint8_t* tileCount = nullptr; uint8_t* slots = nullptr;
     int32_t* dst[3] = {nullptr, nullptr, nullptr}; int32_t dstFill = -1; bool dstValid = false;
     // compaction
-    uint32_t* blockSums = nullptr;      // [3][nBlocks][2]
+    uint32_t* blockSums = nullptr;      // [nBlocks][2]: exclusive prefix of (nibbles, coded tiles) per block of 1024 tiles, same for the 3 planes
+    uint32_t* blockCnt = nullptr;       // [nBlocks][2]: the sums themselves, accumulated by the fused kernel, consumed (and cleared) by the scan
     uint32_t* totals = nullptr;         // [3][2] device
     uint16_t* defsOut = nullptr;        // [3][T8]
     uint8_t*  nibOut = nullptr;         // [3][T8*32 + 8]

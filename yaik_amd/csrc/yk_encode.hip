@@ -522,47 +522,45 @@ __global__ __launch_bounds__(256) void yk_encode_kernel(const YkEncodeParams P) 
 // ------------------------------------------------------------------------------------------------------------------
 #define YK_SCAN_TILE 1024
 
-__global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restrict__ tileCount, size_t T8, uint32_t* __restrict__ blockSums, int nBlocks) {
+// first scan level for the first-generation kernel (the second-generation kernel accumulates these sums itself)
+__global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restrict__ tileCount, size_t T8, uint32_t* __restrict__ blockCnt) {
     __shared__ uint32_t s_tmp[32];
-    const int p = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
-    const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+    const uint32_t c = (i < T8) ? tileCount[i] : 0;                          // plane 0: the counts do not depend on the plane
     uint32_t tot2, totN;
     yk_block_exscan(c ? 1u : 0u, s_tmp, &tot2);
     yk_block_exscan(c, s_tmp, &totN);
-    if (threadIdx.x == 0) { blockSums[((size_t)p * nBlocks + blockIdx.x) * 2] = totN; blockSums[((size_t)p * nBlocks + blockIdx.x) * 2 + 1] = tot2; }
+    if (threadIdx.x == 0) { blockCnt[(size_t)blockIdx.x * 2] = totN; blockCnt[(size_t)blockIdx.x * 2 + 1] = tot2; }
 }
 
-__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockSums, int nBlocks, uint32_t* __restrict__ totals) {
+// second level: exclusive prefix over the per-block sums (consumed and cleared for the next frame), totals for the three
+// planes, and the words of the nibble streams that two blocks share: yk_pack_kernel ORs into those, so they are cleared here;
+// every other word of a stream is written whole.
+__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
+                                                        uint32_t* __restrict__ totals, uint32_t* __restrict__ nib, size_t strideWords) {
     __shared__ uint32_t s_tmp[32];
-    const int p = blockIdx.x;
-    uint32_t* bs = blockSums + (size_t)p * nBlocks * 2;
     uint32_t baseN = 0, baseD = 0;
     for (int start = 0; start < nBlocks; start += 1024) {
         const int i = start + threadIdx.x;
-        const uint32_t n = i < nBlocks ? bs[i * 2] : 0, d = i < nBlocks ? bs[i * 2 + 1] : 0;
+        const uint32_t n = i < nBlocks ? blockCnt[i * 2] : 0, d = i < nBlocks ? blockCnt[i * 2 + 1] : 0;
         uint32_t totN, totD;
         const uint32_t en = yk_block_exscan(n, s_tmp, &totN);
         const uint32_t ed = yk_block_exscan(d, s_tmp, &totD);
-        if (i < nBlocks) { bs[i * 2] = baseN + en; bs[i * 2 + 1] = baseD + ed; }
+        if (i < nBlocks) {
+            blockSums[i * 2] = baseN + en; blockSums[i * 2 + 1] = baseD + ed;
+            blockCnt[i * 2] = 0; blockCnt[i * 2 + 1] = 0;
+            const uint32_t w = (baseN + en) >> 3;
+#pragma unroll
+            for (int p = 0; p < 3; p++) { uint32_t* o = nib + (size_t)p * strideWords; o[w] = 0; if (w) o[w - 1] = 0; }
+        }
         baseN += totN; baseD += totD;
     }
-    if (threadIdx.x == 0) { totals[p * 2] = baseD; totals[p * 2 + 1] = baseN; }
-}
-
-// Words of the nibble streams that two scan blocks share (and the tail word) are OR-ed into by yk_pack_kernel, so they are
-// cleared first; every other word of a stream is written whole.  One thread per scan block.
-__global__ __launch_bounds__(256) void yk_zero_kernel(uint32_t* __restrict__ nib, size_t strideWords, const uint32_t* __restrict__ blockSums, int nBlocks,
-                                                      const uint32_t* __restrict__ totals) {
-    const int p = blockIdx.y;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t* o = nib + (size_t)p * strideWords;
-    if (b < nBlocks) {
-        const uint32_t w = blockSums[((size_t)p * nBlocks + b) * 2] >> 3;
-        o[w] = 0;
-        if (w) o[w - 1] = 0;
+    if (threadIdx.x < 3) {
+        const int p = threadIdx.x;
+        totals[p * 2] = baseD; totals[p * 2 + 1] = baseN;
+        uint32_t* o = nib + (size_t)p * strideWords;
+        const uint32_t w = baseN >> 3; o[w] = 0; o[w + 1] = 0; if (w) o[w - 1] = 0;
     }
-    if (b == 0) { const uint32_t w = totals[p * 2 + 1] >> 3; o[w] = 0; o[w + 1] = 0; if (w) o[w - 1] = 0; }
 }
 
 // One workgroup packs the nibbles of 1024 consecutive tiles: the per-tile slots are read as whole 16-byte vectors, shifted
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
     const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
     const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
     if (totN == 0) return;                                                    // uniform over the workgroup
-    const uint32_t baseN = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2], baseD = blockSums[((size_t)p * nBlocks + blockIdx.x) * 2 + 1];
+    const uint32_t baseN = blockSums[(size_t)blockIdx.x * 2], baseD = blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
     const uint32_t sh0 = baseN & 7u;
     const uint32_t nWords = (sh0 + totN + 7) >> 3;
     for (uint32_t k = threadIdx.x; k < nWords; k += YK_SCAN_TILE) s_out[k] = 0;
@@ -656,6 +654,7 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst)
     P.bounds = (c->nPlanes == 4) ? c->bounds : nullptr;
     for (int i = 0; i < 7; i++) P.bitmap[i] = c->bitmap[i];
     P.coverage = c->coverage; P.tileDef = c->tileDef; P.tileCount = c->tileCount; P.slots = c->slots;
+    P.blockCnt = c->kernelVersion == 2 ? c->blockCnt : nullptr;
     for (int i = 0; i < 3; i++) P.dst[i] = c->dst[i];
     P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
     P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
@@ -669,10 +668,9 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst)
 int yk_launch_pack(yk_ctx* c) {
     const size_t T8 = (size_t)c->tilesW * c->tilesH;
     const int nb = c->nScanBlocks;
-    hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockSums, nb);
-    hipLaunchKernelGGL(yk_scan2_kernel, dim3(3), dim3(1024), 0, c->stream, c->blockSums, nb, c->totals);
-    hipLaunchKernelGGL(yk_zero_kernel, dim3((nb + 255) / 256, 3), dim3(256), 0, c->stream, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4,
-                       c->blockSums, nb, c->totals);
+    if (c->kernelVersion != 2) hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockCnt);
+    hipLaunchKernelGGL(yk_scan2_kernel, dim3(1), dim3(1024), 0, c->stream, c->blockCnt, c->blockSums, nb, c->totals,
+                       reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
     hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, c->tileDef, c->slots, T8, c->blockSums, nb,
                        c->defsOut, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
     YK_HIP(c, hipGetLastError());

@@ -312,6 +312,32 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the wave (0..15)
     const bool writer = (cxl == 0) && (cyl == 0) && tileIn;                  // one lane per tile writes count / def
 
+    // ---- first level of the stream compaction's scan, fused: nibbles and coded tiles per block of 1024 tiles (row-major tile
+    // order = LeftRightOrder).  The counts are the same for the three planes.  A strip holds two runs of 8 consecutive tiles;
+    // when the tile grid is a multiple of 8 wide a run never straddles a scan block and one lane adds the run's sums.
+    {
+        const int n16 = (tileLive && !(P.ablate & 1)) ? (nTop + nBot) : 0;   // nibbles / 16 of this tile-plane
+        if (__ballot(writer && n16 > 0) != 0ULL) {
+            if ((P.tilesW & 7) == 0) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const bool mine = writer && ((cy >> 1) == r);
+                    const unsigned long long b0 = __ballot(mine && (n16 & 1)), b1 = __ballot(mine && (n16 & 2)), b2 = __ballot(mine && (n16 & 4));
+                    const unsigned long long bd = __ballot(mine && n16 > 0);
+                    if (bd != 0ULL && lane == 0) {
+                        const int row = ((BY * 64 + wave * 16) >> 3) + r;
+                        const size_t blk = ((size_t)row * P.tilesW + (size_t)BX * 8) >> 10;
+                        atomicAdd(&P.blockCnt[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
+                        atomicAdd(&P.blockCnt[blk * 2 + 1], (uint32_t)__popcll(bd));
+                    }
+                }
+            } else if (writer && n16 > 0) {
+                atomicAdd(&P.blockCnt[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16);
+                atomicAdd(&P.blockCnt[((size_t)tileIdx >> 10) * 2 + 1], 1u);
+            }
+        }
+    }
+
     if (__ballot(valid) == 0ULL || (P.ablate & 1)) {
         if (writer) {
 #pragma unroll
