@@ -163,7 +163,9 @@ int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
  * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391) */
 int yk_selftest(yk_ctx* c, int which, int* result);
 /* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
- * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums */
+ * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums.
+ * Two flags only select a code path and leave the results exact (used by the parity tests): 16 = re-sum every tile in the
+ * reference's sequential order, 32 = never take the small-range (histogram) path of the range quantiser. */
 int yk_set_ablation(yk_ctx* c, int flags);
 /* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = lane per 4x4 cell, 1 = lane per pixel row.
  * Both produce identical results; kept selectable for A/B timing and as a cross-check in the tests. */

@@ -23,6 +23,22 @@ __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
 // |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
 __device__ __forceinline__ uint32_t y2_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// key = (minDiff << 8) | index of the FIRST nearest LUT entry (the reference's `<` scan, EncoderContext.cpp:873-881):
+// v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n, so a plain min does it.  4-bit modes: the LUT is sorted, two compares against the
+// stored midpoints pick the quarter (ties go down), one per-lane 16-byte LDS read fetches its four entries.
+__device__ __forceinline__ uint32_t y2_search16(const uint32_t* lm, uint32_t H1, uint32_t H2, uint32_t H3, uint32_t x) {
+    const bool c2 = x > H2;
+    const bool c1 = x > (c2 ? H3 : H1);
+    const uint32_t qd = (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
+    const uint4 E = *reinterpret_cast<const uint4*>(lm + qd * 4);
+    return min(min(y2_absdiff(E.x, x), __usad(E.y, x, 1u)), min(__usad(E.z, x, 2u), __usad(E.w, x, 3u))) + qd * 4u;
+}
+__device__ __forceinline__ uint32_t y2_search8(const uint32_t (&e)[8], uint32_t x) {
+    uint32_t key = y2_absdiff(e[0], x);
+#pragma unroll
+    for (int n = 1; n < 8; n++) key = min(key, __usad(e[n], x, (uint32_t)n));
+    return key;
+}
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
@@ -138,6 +154,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
     __shared__ __attribute__((aligned(16))) float s_chain[6][68];           // exact-order fallback, one tile-plane at a time
     __shared__ float s_err[8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_small[256];          // small-range tiles: 16 bins / 16 table entries per tile
 
     const int lane = threadIdx.x;
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
@@ -393,13 +410,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 
             // v<<8 per pixel and a FAST reciprocal (v_rcp_f32, <= 1 ulp): the screening sums below only need ~1e-7 relative
             // accuracy per term; the exact terms (IEEE division) are recomputed in the rare fallback.
-            uint32_t vs[16]; float rv[16];
+            uint32_t vs[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int v = y2_byte(pw[k], p);
-                vs[k] = (uint32_t)v << 8;
-                rv[k] = (valid && v != 0) ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // r = 0 -> the term is exactly +0 (skipped pixel)
-            }
+            for (int k = 0; k < 16; k++) vs[k] = (uint32_t)y2_byte(pw[k], p) << 8;
             // The reference adds the 64 exact terms minDiff/v SEQUENTIALLY in float (:885) and, walking the modes in order, keeps
             // mode m when err_m <= best (:897).  Any summation order of n <= 64 non-negative floats is within gamma_63 = 3.76e-6
             // (relative) of the exact sum and md*rcp(v) is within 2.5e-7 of the correctly rounded quotient, so a screening sum T
@@ -409,58 +422,129 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             // exactly 0 (all terms 0).  Any other case (rare) flags the tile for exact re-summation in the reference's order.
             // minDiff fits a byte: a LUT entry of 256 needs min >= 223, hence |256 - v| <= 33.
             int bestMode = -1; float bestT = 0.0f;
-            uint32_t cLo = 0, cHi = 0, bMd[4] = { 0, 0, 0, 0 };
+            uint32_t cLo = 0, cHi = 0;
             bool amb = false;
+            // Tiles whose valid pixels span at most 16 values (flat areas, mild noise: most of a natural image) do not search per
+            // pixel: the tile's four lanes search the 16 possible values once per mode (4 each), the mode sums come from a 16-bin
+            // histogram (sum over bins of count * minDiff / v), and only the winning mode's table is applied to the pixels.
+            // Wave-uniform choice: taken when every live tile of the strip qualifies for this plane.
+            const bool smallWave = (__ballot(valid && (mx - mn) > 15) == 0ULL) && !(P.ablate & (4 | 32));
+            if (!smallWave) {
+                float rv[16];
 #pragma unroll
-            for (int m = 0; m < 6; m++) {
-                if (m >= P.startMode && !(P.ablate & 4)) {
-                    // key = (minDiff << 8) | index of the first nearest entry (:873-881): v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n
-                    const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
-                    uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
-                    if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
-                    else {
-                        const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
-                        e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+                for (int k = 0; k < 16; k++) {
+                    const int v = y2_byte(pw[k], p);
+                    rv[k] = (valid && v != 0) ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // r = 0 -> the term is exactly +0 (skipped pixel)
+                }
+                uint32_t bMd[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    if (m >= P.startMode && !(P.ablate & 4)) {
+                        // key = (minDiff << 8) | index of the first nearest entry (:873-881): v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n
+                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
+                        uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
+                        if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
+                        else {
+                            const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
+                            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+                        }
+                        float s = 0.0f;
+                        uint32_t mLo = 0, mHi = 0, mMd[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const uint32_t x = vs[k];
+                            const uint32_t key = (m < 3) ? y2_search16(lm, H1, H2, H3, x) : y2_search8(e, x);
+                            // pixel k's index nibble / minDiff byte enter at the top and shift down: after 8 (4) pixels pixel 0 sits lowest
+                            if (k < 8) mLo = __builtin_amdgcn_alignbit(key, mLo, 4); else mHi = __builtin_amdgcn_alignbit(key, mHi, 4);
+                            mMd[k >> 2] = __builtin_amdgcn_perm(key, mMd[k >> 2], 0x05030201u);
+                            s = __fmaf_rn((float)((key >> 8) & 255u), rv[k], s);
+                        }
+                        s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
+                        bool take;
+                        if (bestMode < 0) take = true;
+                        else if (__fmul_rn(s, 1.00002f) < bestT) take = true;                    // surely smaller
+                        else if (__fmul_rn(bestT, 1.00002f) < s) take = false;                   // surely larger
+                        else if (s == bestT) {
+                            if (s == 0.0f) take = true;                                          // both exactly zero
+                            else {
+                                const bool same = !valid || (mMd[0] == bMd[0] && mMd[1] == bMd[1] && mMd[2] == bMd[2] && mMd[3] == bMd[3]);
+                                const bool tileSame = (__ballot(!same) & (0x33ULL << l00)) == 0ULL;   // the tile's four lanes are active together
+                                take = true;
+                                if (!tileSame) amb = true;
+                            }
+                        } else { take = s <= bestT; amb = true; }
+                        if (take) { bestMode = m; bestT = s; cLo = mLo; cHi = mHi; bMd[0] = mMd[0]; bMd[1] = mMd[1]; bMd[2] = mMd[2]; bMd[3] = mMd[3]; }
                     }
-                    float s = 0.0f;
-                    uint32_t mLo = 0, mHi = 0, mMd[4] = { 0, 0, 0, 0 };
+                    __builtin_amdgcn_sched_barrier(0);                           // keep the modes sequential: bounds the live registers
+                }
+            
+            } else {
+                uint32_t* hb = &s_small[tw * 16];
+                *reinterpret_cast<uint4*>(&s_small[lane * 4]) = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) atomicAdd(&hb[y2_byte(pw[k], p) - mn], 1u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint4 cq = *reinterpret_cast<const uint4*>(&hb[j4 * 4]);              // this lane's four bins: values mn + 4*j4 .. +3
+                const uint32_t cnt4[4] = { cq.x, cq.y, cq.z, cq.w };
+                float wgt[4]; uint32_t xs[4], present = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int v = mn + j4 * 4 + i;
+                    xs[i] = (uint32_t)v << 8;
+                    wgt[i] = (cnt4[i] && v != 0) ? __fmul_rn((float)cnt4[i], __builtin_amdgcn_rcpf((float)v)) : 0.0f;   // v == 0: skipped pixel (:884)
+                    present |= cnt4[i] ? (0xFFu << (8 * i)) : 0u;
+                }
+                uint32_t bKey[4] = { 0, 0, 0, 0 }, bMdT = 0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    if (m >= P.startMode) {
+                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
+                        uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
+                        if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
+                        else {
+                            const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
+                            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+                        }
+                        uint32_t key[4], mdT = 0; float s = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            key[i] = (m < 3) ? y2_search16(lm, H1, H2, H3, xs[i]) : y2_search8(e, xs[i]);
+                            mdT |= ((key[i] >> 8) & 255u) << (8 * i);
+                            s = __fmaf_rn((float)((key[i] >> 8) & 255u), wgt[i], s);
+                        }
+                        mdT &= present;                                          // bins no pixel falls in do not take part in the tie test
+                        s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
+                        bool take;
+                        if (bestMode < 0) take = true;
+                        else if (__fmul_rn(s, 1.00002f) < bestT) take = true;
+                        else if (__fmul_rn(bestT, 1.00002f) < s) take = false;
+                        else if (s == bestT) {
+                            if (s == 0.0f) take = true;
+                            else {
+                                const bool tileSame = (__ballot(mdT != bMdT) & (0x33ULL << l00)) == 0ULL;
+                                take = true;
+                                if (!tileSame) amb = true;
+                            }
+                        } else { take = s <= bestT; amb = true; }
+                        if (take) { bestMode = m; bestT = s; bMdT = mdT; bKey[0] = key[0]; bKey[1] = key[1]; bKey[2] = key[2]; bKey[3] = key[3]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the winning mode's table -> the pixels' index nibbles
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<uint4*>(&hb[j4 * 4]) = make_uint4(bKey[0], bKey[1], bKey[2], bKey[3]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (valid) {
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        const uint32_t x = vs[k];
-                        uint32_t key;
-                        if (m < 3) {
-                            const bool c2 = x > H2;
-                            const bool c1 = x > (c2 ? H3 : H1);
-                            const uint32_t qd = (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
-                            const uint4 E = *reinterpret_cast<const uint4*>(lm + qd * 4);
-                            key = min(min(y2_absdiff(E.x, x), __usad(E.y, x, 1u)), min(__usad(E.z, x, 2u), __usad(E.w, x, 3u))) + qd * 4u;
-                        } else {
-                            key = y2_absdiff(e[0], x);
-#pragma unroll
-                            for (int n = 1; n < 8; n++) key = min(key, __usad(e[n], x, (uint32_t)n));
-                        }
-                        // pixel k's index nibble / minDiff byte enter at the top and shift down: after 8 (4) pixels pixel 0 sits lowest
-                        if (k < 8) mLo = __builtin_amdgcn_alignbit(key, mLo, 4); else mHi = __builtin_amdgcn_alignbit(key, mHi, 4);
-                        mMd[k >> 2] = __builtin_amdgcn_perm(key, mMd[k >> 2], 0x05030201u);
-                        s = __fmaf_rn((float)((key >> 8) & 255u), rv[k], s);
+                        const uint32_t key = hb[y2_byte(pw[k], p) - mn];
+                        if (k < 8) cLo = __builtin_amdgcn_alignbit(key, cLo, 4); else cHi = __builtin_amdgcn_alignbit(key, cHi, 4);
                     }
-                    s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
-                    bool take;
-                    if (bestMode < 0) take = true;
-                    else if (__fmul_rn(s, 1.00002f) < bestT) take = true;                    // surely smaller
-                    else if (__fmul_rn(bestT, 1.00002f) < s) take = false;                   // surely larger
-                    else if (s == bestT) {
-                        if (s == 0.0f) take = true;                                          // both exactly zero
-                        else {
-                            const bool same = !valid || (mMd[0] == bMd[0] && mMd[1] == bMd[1] && mMd[2] == bMd[2] && mMd[3] == bMd[3]);
-                            const bool tileSame = (__ballot(!same) & (0x33ULL << l00)) == 0ULL;   // the tile's four lanes are active together
-                            take = true;
-                            if (!tileSame) amb = true;
-                        }
-                    } else { take = s <= bestT; amb = true; }
-                    if (take) { bestMode = m; bestT = s; cLo = mLo; cHi = mHi; bMd[0] = mMd[0]; bMd[1] = mMd[1]; bMd[2] = mMd[2]; bMd[3] = mMd[3]; }
                 }
-                __builtin_amdgcn_sched_barrier(0);                           // keep the modes sequential: bounds the live registers
+                __builtin_amdgcn_wave_barrier();
             }
             if (bestMode < 0) bestMode = 5;                                  // only reachable with the timing-only ablation flag 4
             if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
