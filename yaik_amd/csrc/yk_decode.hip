@@ -30,61 +30,54 @@ __device__ __forceinline__ void yk_dtile_from_bit(const DPassGeo& g, uint32_t po
     y = (int)(blk / g.xBB) * g.bigY + (int)(t / g.tilesPerRow) * (1 << g.sy);
 }
 
-// phase 1: first toucher of every not-yet-loaded lattice point
-__global__ __launch_bounds__(256) void yk_dec_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
+// phase 1: first toucher of every not-yet-loaded lattice point.  One thread per tile slot (bit) of the bitmap.
+__global__ __launch_bounds__(256) void yk_dec_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, DPassGeo g, int w, int h, int latW,
                                                            const uint8_t* __restrict__ loaded, uint32_t* __restrict__ owner) {
-    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= nWords) return;
-    uint32_t bits = bitmap[wi];
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nBits || !((bitmap[pos >> 5] >> (pos & 31)) & 1u)) return;
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    while (bits) {
-        const int b = __ffs(bits) - 1; bits &= bits - 1;
-        const uint32_t pos = (uint32_t)(wi * 32 + b);
-        int x, y; yk_dtile_from_bit(g, pos, x, y);
-        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;
+    int x, y; yk_dtile_from_bit(g, (uint32_t)pos, x, y);
+    if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) return;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
-            if (!loaded[li]) atomicMin(&owner[li], (pos << 2) | (uint32_t)k);
-        }
+    for (int k = 0; k < 4; k++) {
+        const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
+        if (!loaded[li]) atomicMin(&owner[li], ((uint32_t)pos << 2) | (uint32_t)k);
     }
 }
 
-// phase 2 (EMIT=false): corners owned per bitmap word; phase 3 (EMIT=true): pop the colours into the lattice (:97-136)
+// phase 2 (EMIT=false): corners owned per workgroup of 1024 tile slots; phase 3 (EMIT=true): pop the colours into the
+// lattice (:97-136) at the offsets an exclusive scan over the owned-corner counts gives.
 template <bool EMIT>
-__global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
-                                                             uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner, uint32_t* __restrict__ wordCnt,
-                                                             const uint32_t* __restrict__ blockBase, const uint8_t* __restrict__ rgb, size_t rgbBytes,
-                                                             uint8_t* __restrict__ mapRGB) {
+__global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, DPassGeo g, int w, int h, int latW,
+                                                             uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums,
+                                                             const uint8_t* __restrict__ rgb, size_t rgbBytes, uint8_t* __restrict__ mapRGB) {
     __shared__ uint32_t s_tmp[32];
-    const size_t wi = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t word = wi < nWords ? bitmap[wi] : 0u;
+    const size_t pos = (size_t)blockIdx.x * 1024 + threadIdx.x;
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    uint32_t off = 0;
-    if (EMIT) {
-        uint32_t tot;
-        off = (blockBase[blockIdx.x] + yk_block_exscan(wi < nWords ? wordCnt[wi] : 0u, s_tmp, &tot)) * 3u;
-    }
-    uint32_t cnt = 0, bits = word;
-    while (bits) {
-        const int b = __ffs(bits) - 1; bits &= bits - 1;
-        const uint32_t pos = (uint32_t)(wi * 32 + b);
-        int x, y; yk_dtile_from_bit(g, pos, x, y);
-        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;
+    bool set = pos < nBits && ((bitmap[pos >> 5] >> (pos & 31)) & 1u);
+    int x = 0, y = 0;
+    if (set) { yk_dtile_from_bit(g, (uint32_t)pos, x, y); set = !(x + (1 << g.sx) > w || y + (1 << g.sy) > h); }
+    uint32_t own = 0;
+    size_t li[4] = { 0, 0, 0, 0 };
+    if (set) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
-            if (owner[li] == ((pos << 2) | (uint32_t)k)) {
-                if (EMIT) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) mapRGB[li * 3 + c] = (off + c < rgbBytes) ? rgb[off + c] : 0;
-                    loaded[li] = 1;
-                    off += 3;
-                } else cnt++;
-            }
+            li[k] = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
+            own |= (owner[li[k]] == (((uint32_t)pos << 2) | (uint32_t)k)) ? (1u << k) : 0u;
         }
     }
-    if (!EMIT && wi < nWords) wordCnt[wi] = cnt;
+    uint32_t tot;
+    const uint32_t ex = yk_block_exscan((uint32_t)__popc(own), s_tmp, &tot);
+    if (!EMIT) { if (threadIdx.x == 0) blockSums[blockIdx.x] = tot; return; }
+    uint32_t off = (blockSums[blockIdx.x] + ex) * 3u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!((own >> k) & 1u)) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) mapRGB[li[k] * 3 + c] = (off + c < rgbBytes) ? rgb[off + c] : 0;
+        loaded[li[k]] = 1;
+        off += 3;
+    }
 }
 
 // phase 4: integer bilinear fill with truncation (:160-188, :762-781, :1382-1401) + tile4x4Mask marking.
@@ -280,9 +273,9 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     const DPassGeo g = yk_dpass_geo(sx, sy, w);
     const size_t need = ((size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount) >> 3;
     if (bitmapBytes < need) return yk_fail(c, YK_ERR_RANGE, "tile bitmap shorter than the image needs");
-    const size_t nWords = (need + 3) / 4, nb = (nWords + 1023) / 1024;
-    // scratch: [bitmap words][rgb][wordCnt][blockBase][total]
-    const size_t oB = 0, oR = oB + nWords * 4 + 16, oC = (oR + rgbBytes + 19) & ~(size_t)15, oBB = oC + nWords * 4, oT = oBB + nb * 4 + 16;
+    const size_t nWords = (need + 3) / 4, nBits = need * 8, nb = (nBits + 1023) / 1024;
+    // scratch: [bitmap words][rgb][blockSums][total]
+    const size_t oB = 0, oR = oB + nWords * 4 + 16, oBB = (oR + rgbBytes + 19) & ~(size_t)15, oT = oBB + nb * 4 + 16;
     int rc = yk_dec_scratch(c, oT + 64); if (rc) return rc;
     uint8_t* S = c->dScratch;
     YK_HIP(c, hipMemsetAsync(S + oB, 0, nWords * 4, c->stream));
@@ -290,15 +283,14 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     if (rgbBytes) YK_HIP(c, hipMemcpyAsync(S + oR, rgb, rgbBytes, hipMemcpyHostToDevice, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
     const uint32_t* bm = reinterpret_cast<const uint32_t*>(S + oB);
-    uint32_t* wordCnt = reinterpret_cast<uint32_t*>(S + oC); uint32_t* blockBase = reinterpret_cast<uint32_t*>(S + oBB);
+    uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oBB);
     uint32_t* total = reinterpret_cast<uint32_t*>(S + oT);
-    hipLaunchKernelGGL(yk_dec_owner_kernel, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner);
-    hipLaunchKernelGGL(yk_dec_corner_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
-                       wordCnt, (const uint32_t*)nullptr, (const uint8_t*)nullptr, (size_t)0, (uint8_t*)nullptr);
-    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, wordCnt, nWords, blockBase);
-    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockBase, (int)nb, total);
-    hipLaunchKernelGGL(yk_dec_corner_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nWords, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
-                       wordCnt, blockBase, S + oR, rgbBytes, c->dMapRGB);
+    hipLaunchKernelGGL(yk_dec_owner_kernel, dim3((unsigned)((nBits + 255) / 256)), dim3(256), 0, c->stream, bm, nBits, g, w, h, latW, c->dLoaded, c->dLatticeOwner);
+    hipLaunchKernelGGL(yk_dec_corner_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nBits, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
+                       blockSums, (const uint8_t*)nullptr, (size_t)0, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, (int)nb, total);
+    hipLaunchKernelGGL(yk_dec_corner_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nBits, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
+                       blockSums, S + oR, rgbBytes, c->dMapRGB);
     hipLaunchKernelGGL(yk_dec_render_kernel, dim3((unsigned)nWords), dim3(256), 0, c->stream, bm, nWords, g, w, h, latW, c->dMapRGB, c->dPlanes, c->dPlaneSize,
                        w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
     YK_HIP(c, hipGetLastError());
