@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <vector>
@@ -147,10 +148,31 @@ static int writeFile(const char* inPath, const char* outPath) {
     return 0;
 }
 
+// entropy_tool palbench <nColours>: times PaletteCompressor on a synthetic corner stream (6-bit quantised random walk)
+static int palbench(int n) {
+    Bytes in((size_t)n * 3), out((size_t)n * 9 + 64);
+    unsigned s = 12345; int c[3] = { 100, 120, 90 };
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) {
+        s = s * 1664525u + 1013904223u;
+        c[k] += (int)((s >> 24) % 9) - 4; if (c[k] < 0) c[k] = 0; if (c[k] > 250) c[k] = 250;
+        in[(size_t)i * 3 + k] = (u8)(c[k] & ~3);
+    }
+    PaletteResetCodeBook();
+    u32 sz = (u32)out.size();
+    timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    const bool ok = PaletteCompressor(in.data(), (int)in.size(), out.data(), &sz);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    unsigned h = 2166136261u; for (u32 i = 0; i < sz; i++) h = (h ^ out[i]) * 16777619u;
+    printf("PaletteCompressor: %d colours -> %u bytes in %.3f s (%.2f Mcolours/s) ok=%d fnv=%08x\n", n, sz, dt, n / dt / 1e6, (int)ok, h);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     if (!yaikzstd::available()) { fprintf(stderr, "%s\n", yaikzstd::lastError()); return 4; }
     if (argc == 6 && !strcmp(argv[1], "parse")) return parse(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
     if (argc == 4 && !strcmp(argv[1], "write")) return writeFile(argv[2], argv[3]);
+    if (argc == 3 && !strcmp(argv[1], "palbench")) return palbench(atoi(argv[2]));
     fprintf(stderr, "usage: entropy_tool parse <file> <w> <h> <out.blobs> | entropy_tool write <streams.blobs> <out.yaik>\n");
     return 2;
 }
