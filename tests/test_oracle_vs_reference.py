@@ -27,3 +27,14 @@ def test_oracle_equals_reference(oracle_built, name):
     n, h, w = planes.shape
     bad = compare_with_reference(run_reference(planes), oracle_blobs(planes), decode_ok=(w % 16 == 0 and h % 16 == 0))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", [1000, 1003, 1004, 1007, 1009, 1014])
+def test_oracle_equals_reference_on_fuzz_regimes(oracle_built, seed):
+    """The tile regimes of tests/test_gpu_fuzz_parity.py (ranges around 16, values >= 223, zeros, two-level tiles, accept-boundary
+    gradients): the oracle must agree with the unmodified reference there too, so the GPU fuzz test is anchored."""
+    from tests.test_gpu_fuzz_parity import _image
+    size = 256 if seed % 2 else 128                     # the reference's RGBA path needs >= 256 (bad_alloc below)
+    planes = _image(seed, size, 4 if seed % 2 else 3)
+    bad = compare_with_reference(run_reference(planes), oracle_blobs(planes))
+    assert not bad, bad
