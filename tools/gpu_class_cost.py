@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yaik_amd.encoder import HipTileEncoder
 
-W = 8192
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 dev = "cuda"
 x = torch.arange(W, device=dev, dtype=torch.int64)[None, :].expand(W, W)
 y = torch.arange(W, device=dev, dtype=torch.int64)[:, None].expand(W, W)
