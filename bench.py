@@ -190,6 +190,13 @@ def main() -> int:
             result["cpu_baseline"] = {"value": round(cs * cs / 1e6 / (c1 - c0), 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
                                       "sample": f"{cs}x{cs} RGBA {'whole frame' if cs == W else 'centred crop'} of the same workload, "
                                                 f"oracle/liboracle.so (C restatement pinned against the compiled reference), {c1 - c0:.1f} s"}
+            rpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "cpu_ratio.json")
+            if os.path.exists(rpath):                      # ratio restatement / unmodified reference, measured where the reference exists
+                with open(rpath) as f:
+                    ratio = float(json.load(f)["port_over_reference"])
+                result["cpu_baseline"]["port_over_reference"] = ratio
+                result["cpu_baseline"]["reference_equivalent"] = round(result["cpu_baseline"]["value"] / ratio, 3)
+                result["cpu_baseline"]["ratio_source"] = "profiles/cpu_ratio.json (tools/measure_cpu_ratio.py, build container, same stages, one thread)"
         if not args.no_parity and cs == W:
             ok = all(np.array_equal(enc.gradient_bitmap(i), obm[i]) for i in range(7))
             for p in range(3):

@@ -48,9 +48,14 @@ extern "C" size_t __wrap_ZSTD_compress(void* dst, size_t dstCap, const void* src
     Capture c; c.level = level;
     c.data.assign((const u8*)src, (const u8*)src + srcSize);
     gZstd.push_back(c);
-    // Level is irrelevant to the captured raw bytes; use a fast one so the oracle runs in seconds.
-    return __real_ZSTD_compress(dst, dstCap, src, srcSize, 1);
+    // Level is irrelevant to the captured raw bytes; use a fast one so the oracle runs in seconds.  YK_REF_KEEP_LEVEL=1 keeps
+    // the reference's own levels (18 / 21) for the stage timings of tools/measure_cpu_ratio.py.
+    static const bool keep = getenv("YK_REF_KEEP_LEVEL") != NULL;
+    return __real_ZSTD_compress(dst, dstCap, src, srcSize, keep ? level : 1);
 }
+
+#include <time.h>
+static double nowSec() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 
 // ---- blob writer -------------------------------------------------------------------------------
@@ -111,10 +116,13 @@ int main(int argc, char** argv) {
     int meta[3] = { w, h, np };
     blob("meta", meta, sizeof meta);
 
+    double stage[3] = { 0, 0, 0 };                   // seconds: MipPrefilter, 7x FittingQuadSmooth, 3x DynamicTileEncode (4-bpp)
     // ---- a9 alpha tile-reject ----
     if (np == 4) {
         long before = ftell(ctx->outFile);
+        double t0 = nowSec();
         ctx->MipPrefilter(true);
+        stage[0] = nowSec() - t0;
         fflush(ctx->outFile);
         long after = ftell(ctx->outFile);
         std::vector<u8> chunk(after - before);
@@ -136,7 +144,9 @@ int main(int argc, char** argv) {
         gZstd.clear();
         fflush(ctx->outFile);
         long before = ftell(ctx->outFile);
+        double t0 = nowSec();
         counts[i] = ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), preview, false, passes[i][0], passes[i][1]);
+        stage[1] += nowSec() - t0;
         if (!gZstd.empty()) bitmaps[i] = gZstd[0].data;          // first ZSTD_compress of the pass = raw tile bitmap (:4266)
         else {
             // No tile accepted: the pass writes no chunk (:4239); its bitmap is all zero by construction (:3777).
@@ -179,7 +189,9 @@ int main(int argc, char** argv) {
             BoundingBox full = dst->GetRect();
             dst->Fill(full, -1);
             gZstd.clear();
+            double t0 = nowSec();
             ctx->DynamicTileEncode(m == 1, img->GetPlane(p), dst, false, false, false, false);
+            if (m == 0) stage[2] += nowSec() - t0;
             // :4519 tile definitions, :4533 nibble index stream
             blob(nm("plnt_defs", m, p), gZstd[0].data.data(), gZstd[0].data.size());
             blob(nm("plnt_idx", m, p), gZstd[1].data.data(), gZstd[1].data.size());
@@ -187,6 +199,8 @@ int main(int argc, char** argv) {
             delete dst;
         }
     }
+
+    blob("stage_seconds", stage, sizeof stage);
 
     // ---- a15 live 1-D range path ----
     size_t cap = (size_t)w * h * 3 + 64;

@@ -5,7 +5,7 @@ import numpy as np
 from oracle.pyoracle import (PASSES, OracleDecoder, OracleEncoder, palette_decompress)
 
 # blobs whose bytes depend on uninitialised reference memory or that the fixtures do not keep
-SKIP = {"meta", "mip_chunk", "dec_mapRGB", "chunks_file"}      # chunks_file: see tests/test_host_chunks.py
+SKIP = {"meta", "mip_chunk", "dec_mapRGB", "chunks_file", "stage_seconds"}      # chunks_file: see tests/test_host_chunks.py
 
 
 def oracle_blobs(planes: np.ndarray) -> dict:
