@@ -134,7 +134,8 @@ int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix,
  * that a single RCCL gather can concatenate the per-stripe / per-frame tile maps.  Layout, every section padded to
  * 16 bytes: 7 gradient bitmaps | keep flags (1 byte per 16x16 tile, RGBA only) | per plane: tile defs (u16), nibbles.
  * sizes[0..6] bitmap bytes, sizes[7] keep bytes, sizes[8+2p] = nDefs(p), sizes[9+2p] = nNibbles(p), sizes[14] = total
- * bytes written.  Synchronises (the stream sizes live on the device).  cap: see yk_export_capacity. */
+ * bytes written.  One kernel packs all sections; the call returns after the stream has been synchronised, i.e. the buffer
+ * is complete and may be handed to another runtime instance / RCCL.  cap >= yk_export_capacity. */
 size_t yk_export_capacity(const yk_ctx* c);
 int    yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]);
 

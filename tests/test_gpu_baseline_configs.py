@@ -120,3 +120,24 @@ def test_c5_16384_rgba_stripes_and_decode_round_trip(hip):
         # nibble streams concatenate with a 4-bit shift; compare through a running hash of the nibble sequence to bound memory
         cat, total = ykd.concat_nibble_streams(nibs[p], nns[p])
         assert total == wnn and np.array_equal(cat, wn)
+
+
+@pytest.mark.parametrize("wh,npl", [((72, 40), 3), ((200, 136), 3), ((128, 128), 4)])
+def test_export_layout_on_small_and_odd_tile_grids(hip, wh, npl):
+    """yk_export_tile_maps (one packing kernel) on tile grids whose per-plane sections are not 16-byte aligned in HBM"""
+    import torch
+    from tests.images import edge_image
+    hip.set_image(edge_image(wh[0], wh[1], "mixed", npl))
+    if npl == 4:
+        hip.mip_prefilter()
+    hip.encode(3, False, False)
+    blob = torch.full((hip.export_capacity() + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    sizes = hip.export_tile_maps(blob)
+    host = blob.cpu().numpy()
+    assert (host[int(sizes[14]):] == 0xAB).all()                         # nothing written past the payload
+    parts = ykd.split_blob(sizes, host[: int(sizes[14])])
+    for i in range(7):
+        assert np.array_equal(parts["bitmaps"][i], hip.gradient_bitmap(i))
+    for p in range(3):
+        d, nb, nn = hip.range_streams(p)
+        assert np.array_equal(parts["defs"][p], d) and np.array_equal(parts["nibbles"][p], nb) and parts["n_nibbles"][p] == nn

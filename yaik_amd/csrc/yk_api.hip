@@ -19,7 +19,7 @@ static void yk_free_image(yk_ctx* c) {
     for (int i = 0; i < 7; i++) F(c->bitmap[i]);
     F(c->coverage); F(c->tileDef); F(c->tileCount); F(c->slots);
     for (int i = 0; i < 3; i++) F(c->dst[i]);
-    F(c->blockSums); F(c->blockCnt); F(c->totals); F(c->defsOut); F(c->nibOut);
+    F(c->blockSums); F(c->blockCnt); F(c->totals); F(c->exportSizes); F(c->defsOut); F(c->nibOut);
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
@@ -376,30 +376,57 @@ size_t yk_export_capacity(const yk_ctx* c) {
     return n;
 }
 
+// One launch packs all sections: blockIdx.y = section.  The lengths of the six stream sections live on the device (scan totals),
+// so every workgroup derives its section's offset itself and workgroup (0,0) publishes the 15 sizes for the host.
+struct YkExportDesc {
+    const uint8_t* src[14];
+    unsigned long long fixedBytes[8];       // 7 bitmaps + keep flags
+    const uint32_t* totals;                 // [3][2]: coded tiles, nibbles per plane
+    unsigned long long* sizesOut;           // [15]
+};
+
+__global__ __launch_bounds__(256) void yk_export_kernel(YkExportDesc d, uint8_t* __restrict__ dst) {
+    const int sec = blockIdx.y;
+    unsigned long long n[14], off = 0, mine = 0, myOff = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) n[i] = d.fixedBytes[i];
+#pragma unroll
+    for (int p = 0; p < 3; p++) { n[8 + 2 * p] = (unsigned long long)d.totals[p * 2] * 2; n[9 + 2 * p] = ((unsigned long long)d.totals[p * 2 + 1] + 1) / 2; }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { if (i == sec) { mine = n[i]; myOff = off; } off += (n[i] + 15) & ~15ULL; }
+    if (sec == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 8; i++) d.sizesOut[i] = n[i];
+        for (int p = 0; p < 3; p++) { d.sizesOut[8 + 2 * p] = d.totals[p * 2]; d.sizesOut[9 + 2 * p] = d.totals[p * 2 + 1]; }
+        d.sizesOut[14] = off;
+    }
+    const uint8_t* src = d.src[sec];
+    uint8_t* o = dst + myOff;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // section offsets are multiples of 16; a source is too unless the tile grid is tiny and odd (defs of plane 1, 2)
+    unsigned long long nVec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 ? (mine >> 4) : 0;
+    for (size_t i = t0; i < nVec; i += stride) reinterpret_cast<uint4*>(o)[i] = reinterpret_cast<const uint4*>(src)[i];
+    const unsigned long long padded = (mine + 15) & ~15ULL;
+    for (unsigned long long i = (nVec << 4) + t0; i < padded; i += stride) o[i] = i < mine ? src[i] : 0;   // unaligned source / tail / zero padding
+}
+
 int yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]) {
     if (!c || !devDst || !sizes) return YK_ERR_BAD_ARG;
     if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    if (cap < yk_export_capacity(c)) return yk_fail(c, YK_ERR_RANGE, "export buffer smaller than yk_export_capacity");
     YK_HIP(c, hipSetDevice(c->device));
-    uint32_t t[6];
-    YK_HIP(c, hipMemcpyAsync(t, c->totals, sizeof t, hipMemcpyDeviceToHost, c->stream));
-    YK_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->exportSizes) YK_HIP(c, hipMalloc(&c->exportSizes, 16 * sizeof(unsigned long long)));
     const size_t T8 = (size_t)c->tilesW * c->tilesH;
-    uint8_t* d = (uint8_t*)devDst; size_t off = 0;
-    auto put = [&](const void* src, size_t n) -> int {
-        const size_t padded = (n + 15) & ~(size_t)15;
-        if (off + padded > cap) return yk_fail(c, YK_ERR_RANGE, "export buffer too small");
-        if (n) { hipError_t e = hipMemcpyAsync(d + off, src, n, hipMemcpyDeviceToDevice, c->stream); if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "export copy", e); }
-        off += padded; return YK_OK;
-    };
-    for (int i = 0; i < 7; i++) { sizes[i] = c->bitmapBytes[i]; int rc = put(c->bitmap[i], c->bitmapBytes[i]); if (rc) return rc; }
-    sizes[7] = (c->nPlanes == 4) ? (size_t)c->mtW * c->mtH : 0;
-    { int rc = put(c->keep, sizes[7]); if (rc) return rc; }
-    for (int p = 0; p < 3; p++) {
-        sizes[8 + 2 * p] = t[p * 2]; sizes[9 + 2 * p] = t[p * 2 + 1];
-        int rc = put(c->defsOut + p * T8, (size_t)t[p * 2] * 2); if (rc) return rc;
-        rc = put(c->nibOut + p * c->nibStride, ((size_t)t[p * 2 + 1] + 1) / 2); if (rc) return rc;
-    }
-    sizes[14] = off;
+    YkExportDesc d;
+    for (int i = 0; i < 7; i++) { d.src[i] = c->bitmap[i]; d.fixedBytes[i] = c->bitmapBytes[i]; }
+    d.src[7] = c->keep; d.fixedBytes[7] = (c->nPlanes == 4) ? (unsigned long long)c->mtW * c->mtH : 0;
+    for (int p = 0; p < 3; p++) { d.src[8 + 2 * p] = reinterpret_cast<const uint8_t*>(c->defsOut + p * T8); d.src[9 + 2 * p] = c->nibOut + p * c->nibStride; }
+    d.totals = c->totals; d.sizesOut = c->exportSizes;
+    hipLaunchKernelGGL(yk_export_kernel, dim3(128, 14), dim3(256), 0, c->stream, d, (uint8_t*)devDst);
+    YK_HIP(c, hipGetLastError());
+    unsigned long long h[15];
+    YK_HIP(c, hipMemcpyAsync(h, c->exportSizes, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));                 // the buffer is complete when this returns (the caller may hand it to another runtime / RCCL)
+    for (int i = 0; i < 15; i++) sizes[i] = h[i];
     return YK_OK;
 }
 
