@@ -83,22 +83,32 @@ def main() -> int:
     # is double-buffered so that the RCCL transfer of frame i rides under the encode kernels of frame i+1.
     pipe = ykd.TileMapGatherPipeline(dist, comm_dev, enc.export_capacity(), dst=0, staging_device=dev) if world > 1 else None
 
+    deferred = []                              # (nbytes, sizes) of exports whose gather is launched under the NEXT step's kernels
+
     def step():
         for e in encs:                         # no host synchronisation in here: K frames are in flight on K streams
             e.alpha_reject()
             e.alpha_finish(None)
             e.encode(3, args.mode3, False)
         if world > 1:
-            for e in encs:
+            # host work of the previous step's collective (size table, launches) rides under this step's kernels
+            while deferred:
+                pipe.submit(*deferred.pop(0))
+            for j, e in enumerate(encs):
                 blob, _ = pipe.acquire()
-                sizes = e.export_tile_maps(blob)
-                pipe.submit(int(sizes[14]), sizes)
+                sizes = e.export_tile_maps(blob)   # one packing kernel + a stream sync: the blob is complete on return
+                if j + 1 < len(encs):
+                    pipe.submit(int(sizes[14]), sizes)
+                else:
+                    deferred.append((int(sizes[14]), sizes))
 
     def fence():
         torch.cuda.synchronize()
         for e in encs:
             e.synchronize()
         if world > 1:
+            while deferred:
+                pipe.submit(*deferred.pop(0))
             pipe.flush()                       # every gather has landed on rank 0 before the clock stops
             dist.barrier()
         torch.cuda.synchronize()
