@@ -45,9 +45,10 @@ enum yk_status {
 int         yk_create(int device, yk_ctx** out);
 void        yk_destroy(yk_ctx* c);
 const char* yk_last_error(const yk_ctx* c);
-/* NULL = the handle's own (non-blocking) stream.  A stream handle is only meaningful inside the HIP runtime instance that
- * created it: a process that also loads a second copy of the runtime (e.g. the one bundled with PyTorch) must not pass that
- * copy's streams here, and must fence hand-overs between the two on the host (their null streams are not ordered either). */
+/* NULL = the handle's own non-blocking stream (the default).  That stream is NOT ordered against the null stream or any
+ * other stream of the process: fence hand-overs of buffers on the host, or pass the producer's / consumer's stream here.
+ * A stream handle is only meaningful inside the HIP runtime instance that created it (a process that loads this library
+ * before a framework's bundled copy of the runtime ends up with two instances; load the framework first). */
 int         yk_set_stream(yk_ctx* c, void* hipStream);
 int         yk_synchronize(yk_ctx* c);
 int         yk_device_count(void);                          /* no device initialisation side effects beyond hipGetDeviceCount */

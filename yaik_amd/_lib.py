@@ -88,8 +88,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise YaikError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback for the product path)")
-        # PyTorch bundles its own HIP runtime; when both live in one process the bundled one must come up first (the
-        # reverse order leaves torch with "No HIP GPUs are available").  torch is only plumbing here, so this is best effort.
+        # PyTorch bundles its own HIP runtime (same SONAME as the system one).  Brought up first, this library binds to that
+        # one instance; in the reverse order the process holds two and torch fails with "No HIP GPUs are available".
+        # torch is only plumbing here, so this is best effort.
         try:
             import torch
             if torch.cuda.is_available():

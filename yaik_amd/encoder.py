@@ -61,10 +61,10 @@ class HipTileEncoder:
             assert planes.dtype == torch.int32 and planes.is_cuda and planes.is_contiguous()
             base = planes.data_ptr()
             ptrs = (C.c_void_p * 4)(*[base + i * rows * w * 4 if i < n else None for i in range(4)])
-            # PyTorch ships its own copy of the HIP runtime; the library is linked against the system one.  Stream handles and
-            # the ordering of the two null streams do not carry across runtime instances (measured: a kernel launched here
-            # right after a torch kernel reads stale planes), so the hand-over is a host-side fence and the handle keeps its
-            # own stream.  Results handed back to torch are fenced the same way (every getter / export synchronises).
+            # The handle launches on its own non-blocking stream, which is not ordered against torch's streams (measured: a kernel
+            # launched here right after a torch kernel reads stale planes).  The hand-over is therefore a host-side fence; results
+            # handed back to torch are fenced the same way (every getter and yk_export_tile_maps synchronise the handle's stream).
+            # (_lib.lib() brings torch's bundled HIP runtime up first, so that this library binds to the same runtime instance.)
             torch.cuda.current_stream(planes.device).synchronize()
             _chk(self._h, L.yk_bind_device_planes(self._h, ptrs, w))
         else:
