@@ -83,7 +83,8 @@ def main() -> int:
     # is double-buffered so that the RCCL transfer of frame i rides under the encode kernels of frame i+1.
     pipe = ykd.TileMapGatherPipeline(dist, comm_dev, enc.export_capacity(), dst=0, staging_device=dev) if world > 1 else None
 
-    deferred = []                              # (nbytes, sizes) of exports whose gather is launched under the NEXT step's kernels
+    use_async = world > 1 and not rehearsal    # device-side hand-over to the communicator's stream (needs the payload in HBM)
+    deferred = []                              # rehearsal only: (nbytes, sizes) of exports whose gather is launched under the next step
 
     def step():
         for e in encs:                         # no host synchronisation in here: K frames are in flight on K streams
@@ -91,16 +92,21 @@ def main() -> int:
             e.alpha_finish(None)
             e.encode(3, args.mode3, False)
         if world > 1:
-            # host work of the previous step's collective (size table, launches) rides under this step's kernels
             while deferred:
                 pipe.submit(*deferred.pop(0))
             for j, e in enumerate(encs):
-                blob, _ = pipe.acquire()
-                sizes = e.export_tile_maps(blob)   # one packing kernel + a stream sync: the blob is complete on return
-                if j + 1 < len(encs):
-                    pipe.submit(int(sizes[14]), sizes)
+                blob, _ = pipe.acquire()       # waits for the gather that used this buffer two submits ago
+                if use_async and pipe.pad != 0:
+                    # one packing kernel behind the encode on the handle's stream; the RCCL ops are enqueued behind torch's current
+                    # stream, which is made to wait for that kernel on the device: the host never waits for the frame it just queued
+                    e.export_tile_maps_async(blob, pipe.meta_tensor(), torch.cuda.current_stream(dev).cuda_stream)
+                    pipe.submit()
                 else:
-                    deferred.append((int(sizes[14]), sizes))
+                    sizes = e.export_tile_maps(blob)   # packing kernel + stream sync: the blob is complete on return
+                    if use_async or j + 1 < len(encs):
+                        pipe.submit(int(sizes[14]), sizes)
+                    else:
+                        deferred.append((int(sizes[14]), sizes))
 
     def fence():
         torch.cuda.synchronize()

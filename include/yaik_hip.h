@@ -51,6 +51,11 @@ const char* yk_last_error(const yk_ctx* c);
  * before a framework's bundled copy of the runtime ends up with two instances; load the framework first). */
 int         yk_set_stream(yk_ctx* c, void* hipStream);
 int         yk_synchronize(yk_ctx* c);
+/* Device-side ordering against another stream of the SAME runtime instance (0 = the null stream), instead of a host fence:
+ * yk_stream_wait_for: everything queued on the handle's stream from now on waits for what `producerStream` holds now;
+ * yk_stream_handoff:  everything queued on `consumerStream` from now on waits for what the handle's stream holds now. */
+int         yk_stream_wait_for(yk_ctx* c, void* producerStream);
+int         yk_stream_handoff(yk_ctx* c, void* consumerStream);
 int         yk_device_count(void);                          /* no device initialisation side effects beyond hipGetDeviceCount */
 
 /* ---- image binding:  EncoderContext::SetImageToEncode (encoder/EncoderContext.cpp:1227) ------
@@ -139,6 +144,10 @@ int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix,
  * is complete and may be handed to another runtime instance / RCCL.  cap >= yk_export_capacity. */
 size_t yk_export_capacity(const yk_ctx* c);
 int    yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]);
+/* The same without a host synchronisation, for pipelines that keep the size table on the device: devMeta16 (device, 16 x u64)
+ * receives {total payload bytes, sizes[0..14]}; work queued afterwards on `consumerStream` (same runtime instance, 0 = null
+ * stream; e.g. the stream a RCCL collective is enqueued behind) sees the finished buffer and table (yk_stream_handoff). */
+int    yk_export_tile_maps_async(yk_ctx* c, void* devDst, size_t cap, void* devMeta16, void* consumerStream);
 
 /* ---- decode side: the loops behind YAIK_DecodeImage's chunk switch (decoder/YAIK_API.cpp:731-1303) ----
  * Buffers mirror YAIK_Instance (include/YAIK_private.h:26-54): planeR/G/B u8 in 8x8 tiles, mapRGB lattice,

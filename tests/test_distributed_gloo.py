@@ -107,7 +107,12 @@ def _pipe_worker(rank, world, port, q):
                 take(done)
             buf[:n] = torch.from_numpy(payload(step, rank, n))
             sz = np.zeros(15, np.int64); sz[14] = n; sz[0] = step
-            pipe.submit(n, sz)
+            if step == 0 or step % 2:
+                pipe.submit(n, sz)                              # size table from the host
+            else:
+                m = pipe.meta_tensor()                          # size table already "on the device" (asynchronous exporter)
+                m[0] = n; m[1:16] = torch.from_numpy(sz)
+                pipe.submit()
         for done in pipe.flush():
             take(done)
         assert len(results) == len(sizes_per_step), len(results)

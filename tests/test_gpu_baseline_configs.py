@@ -141,3 +141,26 @@ def test_export_layout_on_small_and_odd_tile_grids(hip, wh, npl):
     for p in range(3):
         d, nb, nn = hip.range_streams(p)
         assert np.array_equal(parts["defs"][p], d) and np.array_equal(parts["nibbles"][p], nb) and parts["n_nibbles"][p] == nn
+
+
+def test_async_export_is_ordered_before_the_consumer_stream(hip):
+    """yk_export_tile_maps_async + yk_stream_handoff: torch work queued after the call (as a RCCL collective would be) sees the
+    finished payload and size table without any host synchronisation in between."""
+    import torch
+    from yaik_amd.synth import synth_planes
+    hip.set_image(synth_planes(2048, n_planes=4))
+    hip.mip_prefilter()
+    hip.encode(3, False, False)
+    ref = torch.zeros(hip.export_capacity(), dtype=torch.uint8, device="cuda")
+    sizes = hip.export_tile_maps(ref)
+    n = int(sizes[14])
+    for rep in range(5):
+        hip.encode(3, False, False)                                      # the export must queue behind this on the handle's stream
+        blob = torch.full((hip.export_capacity(),), 0x5A, dtype=torch.uint8, device="cuda")
+        meta = torch.full((16,), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        hip.export_tile_maps_async(blob, meta, torch.cuda.current_stream().cuda_stream)
+        got_blob = blob[:n].clone()                                      # torch kernels on the consumer stream, no host fence
+        got_meta = meta.clone()
+        assert got_meta.cpu().tolist() == [n] + [int(v) for v in sizes]
+        assert torch.equal(got_blob, ref[:n])

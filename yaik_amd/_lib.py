@@ -65,6 +65,9 @@ SIGNATURES = {
     "yk_range1d_streams": (C.c_int, [vp, vp, sz, szp, vp, sz, szp]),
     "yk_export_capacity": (sz, [vp]),
     "yk_export_tile_maps": (C.c_int, [vp, vp, sz, vp]),
+    "yk_export_tile_maps_async": (C.c_int, [vp, vp, sz, vp, vp]),
+    "yk_stream_wait_for": (C.c_int, [vp, vp]),
+    "yk_stream_handoff": (C.c_int, [vp, vp]),
     "yk_decode_begin": (C.c_int, [vp, C.c_int, C.c_int]),
     "yk_decode_gradient": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz]),
     "yk_decode_1d": (C.c_int, [vp, vp, sz, vp, sz, C.c_int]),

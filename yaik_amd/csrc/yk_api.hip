@@ -58,6 +58,7 @@ void yk_destroy(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
+    if (c->evHandoff) (void)hipEventDestroy(c->evHandoff);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -382,7 +383,7 @@ struct YkExportDesc {
     const uint8_t* src[14];
     unsigned long long fixedBytes[8];       // 7 bitmaps + keep flags
     const uint32_t* totals;                 // [3][2]: coded tiles, nibbles per plane
-    unsigned long long* sizesOut;           // [15]
+    unsigned long long* sizesOut;           // [16]: total payload bytes, then the 15 section sizes
 };
 
 __global__ __launch_bounds__(256) void yk_export_kernel(YkExportDesc d, uint8_t* __restrict__ dst) {
@@ -395,9 +396,10 @@ __global__ __launch_bounds__(256) void yk_export_kernel(YkExportDesc d, uint8_t*
 #pragma unroll
     for (int i = 0; i < 14; i++) { if (i == sec) { mine = n[i]; myOff = off; } off += (n[i] + 15) & ~15ULL; }
     if (sec == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int i = 0; i < 8; i++) d.sizesOut[i] = n[i];
-        for (int p = 0; p < 3; p++) { d.sizesOut[8 + 2 * p] = d.totals[p * 2]; d.sizesOut[9 + 2 * p] = d.totals[p * 2 + 1]; }
-        d.sizesOut[14] = off;
+        d.sizesOut[0] = off;
+        for (int i = 0; i < 8; i++) d.sizesOut[1 + i] = n[i];
+        for (int p = 0; p < 3; p++) { d.sizesOut[9 + 2 * p] = d.totals[p * 2]; d.sizesOut[10 + 2 * p] = d.totals[p * 2 + 1]; }
+        d.sizesOut[15] = off;
     }
     const uint8_t* src = d.src[sec];
     uint8_t* o = dst + myOff;
@@ -409,24 +411,53 @@ __global__ __launch_bounds__(256) void yk_export_kernel(YkExportDesc d, uint8_t*
     for (unsigned long long i = (nVec << 4) + t0; i < padded; i += stride) o[i] = i < mine ? src[i] : 0;   // unaligned source / tail / zero padding
 }
 
-int yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]) {
-    if (!c || !devDst || !sizes) return YK_ERR_BAD_ARG;
+static int yk_export_launch(yk_ctx* c, void* devDst, size_t cap, unsigned long long* devMeta16) {
     if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
     if (cap < yk_export_capacity(c)) return yk_fail(c, YK_ERR_RANGE, "export buffer smaller than yk_export_capacity");
     YK_HIP(c, hipSetDevice(c->device));
-    if (!c->exportSizes) YK_HIP(c, hipMalloc(&c->exportSizes, 16 * sizeof(unsigned long long)));
     const size_t T8 = (size_t)c->tilesW * c->tilesH;
     YkExportDesc d;
     for (int i = 0; i < 7; i++) { d.src[i] = c->bitmap[i]; d.fixedBytes[i] = c->bitmapBytes[i]; }
     d.src[7] = c->keep; d.fixedBytes[7] = (c->nPlanes == 4) ? (unsigned long long)c->mtW * c->mtH : 0;
     for (int p = 0; p < 3; p++) { d.src[8 + 2 * p] = reinterpret_cast<const uint8_t*>(c->defsOut + p * T8); d.src[9 + 2 * p] = c->nibOut + p * c->nibStride; }
-    d.totals = c->totals; d.sizesOut = c->exportSizes;
+    d.totals = c->totals; d.sizesOut = devMeta16;
     hipLaunchKernelGGL(yk_export_kernel, dim3(128, 14), dim3(256), 0, c->stream, d, (uint8_t*)devDst);
     YK_HIP(c, hipGetLastError());
-    unsigned long long h[15];
+    return YK_OK;
+}
+
+int yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]) {
+    if (!c || !devDst || !sizes) return YK_ERR_BAD_ARG;
+    if (!c->exportSizes) { YK_HIP(c, hipSetDevice(c->device)); YK_HIP(c, hipMalloc(&c->exportSizes, 16 * sizeof(unsigned long long))); }
+    int rc = yk_export_launch(c, devDst, cap, c->exportSizes); if (rc) return rc;
+    unsigned long long h[16];
     YK_HIP(c, hipMemcpyAsync(h, c->exportSizes, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    YK_HIP(c, hipStreamSynchronize(c->stream));                 // the buffer is complete when this returns (the caller may hand it to another runtime / RCCL)
-    for (int i = 0; i < 15; i++) sizes[i] = h[i];
+    YK_HIP(c, hipStreamSynchronize(c->stream));                 // the buffer is complete when this returns
+    for (int i = 0; i < 15; i++) sizes[i] = h[1 + i];
+    return YK_OK;
+}
+
+int yk_export_tile_maps_async(yk_ctx* c, void* devDst, size_t cap, void* devMeta16, void* consumerStream) {
+    if (!c || !devDst || !devMeta16) return YK_ERR_BAD_ARG;
+    int rc = yk_export_launch(c, devDst, cap, reinterpret_cast<unsigned long long*>(devMeta16)); if (rc) return rc;
+    return yk_stream_handoff(c, consumerStream);
+}
+
+int yk_stream_handoff(yk_ctx* c, void* consumerStream) {
+    if (!c) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->evHandoff) YK_HIP(c, hipEventCreateWithFlags(&c->evHandoff, hipEventDisableTiming));
+    YK_HIP(c, hipEventRecord(c->evHandoff, c->stream));
+    YK_HIP(c, hipStreamWaitEvent((hipStream_t)consumerStream, c->evHandoff, 0));
+    return YK_OK;
+}
+
+int yk_stream_wait_for(yk_ctx* c, void* producerStream) {
+    if (!c) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->evHandoff) YK_HIP(c, hipEventCreateWithFlags(&c->evHandoff, hipEventDisableTiming));
+    YK_HIP(c, hipEventRecord(c->evHandoff, (hipStream_t)producerStream));
+    YK_HIP(c, hipStreamWaitEvent(c->stream, c->evHandoff, 0));
     return YK_OK;
 }
 

@@ -63,7 +63,8 @@ struct yk_ctx {
     uint32_t* blockSums = nullptr;      // [nBlocks][2]: exclusive prefix of (nibbles, coded tiles) per block of 1024 tiles, same for the 3 planes
     uint32_t* blockCnt = nullptr;       // [nBlocks][2]: the sums themselves, accumulated by the fused kernel, consumed (and cleared) by the scan
     uint32_t* totals = nullptr;         // [3][2] device
-    unsigned long long* exportSizes = nullptr;   // [15] section sizes of the last yk_export_tile_maps
+    unsigned long long* exportSizes = nullptr;   // [16] total + section sizes of the last yk_export_tile_maps
+    hipEvent_t evHandoff = nullptr;              // yk_stream_handoff / yk_stream_wait_for
     uint16_t* defsOut = nullptr;        // [3][T8]
     uint8_t*  nibOut = nullptr;         // [3][T8*32 + 8]
     size_t nibStride = 0;

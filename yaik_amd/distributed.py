@@ -103,14 +103,24 @@ class TileMapGatherPipeline:
         slot = self.step & 1
         return self.blobs[slot], self._retire(slot)
 
-    def submit(self, nbytes: int, sizes) -> None:
+    def meta_tensor(self):
+        """int64[16] device tensor of the current buffer: {payload bytes, sizes[0..14]} — the target of an asynchronous export."""
+        return self.meta[self.step & 1]
+
+    def submit(self, nbytes: int | None = None, sizes=None) -> None:
+        """Launch the gather of the acquired buffer.  With (nbytes, sizes) the size table comes from the host; without, it was
+        already written on the device (meta_tensor(), ordered before the communicator's stream by the exporter) — that form
+        needs an agreed length, i.e. at least one earlier submit with host sizes."""
         import torch
         slot = self.step & 1
         assert self.work[slot] is None, "acquire() the buffer before exporting into it"
         dist = self.dist
         m = self.meta[slot]
-        m[0] = int(nbytes)
-        m[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=m.device)
+        if nbytes is not None:
+            m[0] = int(nbytes)
+            m[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=m.device)
+        else:
+            assert self.pad != 0, "the first submit of a pipeline needs the sizes on the host"
         if self.pad == 0:                                   # first step: agree on a length once, synchronously
             dist.all_gather(self.metas[slot], m)
             self.pad = self._roundup(int(torch.stack(self.metas[slot])[:, 0].max().item()))

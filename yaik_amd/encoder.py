@@ -187,6 +187,12 @@ class HipTileEncoder:
         _chk(self._h, lib().yk_export_tile_maps(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(), sizes.ctypes.data))
         return sizes
 
+    def export_tile_maps_async(self, dev_buffer, dev_meta16, consumer_stream: int = 0) -> None:
+        """No host synchronisation: dev_meta16 (torch int64[16] cuda tensor) receives {total bytes, sizes[0..14]}; work queued
+        afterwards on `consumer_stream` (a hipStream_t of the same runtime, 0 = null stream) sees buffer and table complete."""
+        _chk(self._h, lib().yk_export_tile_maps_async(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(),
+                                                      C.c_void_p(dev_meta16.data_ptr()), C.c_void_p(consumer_stream)))
+
     def kernel_ms(self) -> dict:
         e, a, p = C.c_float(), C.c_float(), C.c_float()
         _chk(self._h, lib().yk_last_kernel_ms(self._h, C.byref(e), C.byref(a), C.byref(p)))
