@@ -145,6 +145,35 @@ def main() -> int:
     for n in kms:
         kms[n] /= max(1, args.steps)
 
+    # ---- N > 1: check the collective's data path outside the timed region: every rank's payload must arrive on rank 0 byte for
+    # byte (compared through 64-bit checksums), for the host-fenced export and for the device-side hand-over
+    gather_check = None
+    if world > 1:
+        def checksum(t):
+            v = t.to(torch.int64)
+            idx = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64)
+            return int(((v * (idx % 65521 + 1)).sum() + v.numel()).item())
+        bad = []
+        for mode in (("host", "device") if use_async else ("host",)):
+            blob, _ = pipe.acquire()
+            if mode == "host":
+                sizes = enc.export_tile_maps(blob)
+                pipe.submit(int(sizes[14]), sizes)
+            else:
+                enc.export_tile_maps_async(blob, pipe.meta_tensor(), torch.cuda.current_stream(dev).cuda_stream)
+                pipe.submit()
+            res = pipe.flush()[-1]
+            ref_sizes = enc.export_tile_maps(blob)                               # blob is free again after the flush
+            mine = torch.tensor([checksum(blob[: int(ref_sizes[14])]), int(ref_sizes[14])], dtype=torch.int64, device=comm_dev)
+            allsums = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allsums, mine)
+            if rank == 0:
+                for r, (sz, payload) in enumerate(res):
+                    want = allsums[r].cpu().tolist()
+                    if int(sz[14]) != want[1] or checksum(payload.to(dev)) != want[0]:
+                        bad.append(f"{mode}: rank {r}")
+        gather_check = "ok" if not bad else "MISMATCH " + ", ".join(bad)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -185,6 +214,11 @@ def main() -> int:
                    "parallelism": f"frame-sharded x{world}, one RCCL gather of tile maps" if world > 1 else "single GPU"},
         "roofline": roofline,
     }
+    if gather_check is not None:
+        result["gather_check"] = gather_check
+        if gather_check != "ok":
+            print(json.dumps(result))
+            return 1
 
     # ---- parity at full size + CPU baseline (rank 0, N = 1 only; the oracle is the checker, never the thing shipped) ------
     if world == 1 and not (args.no_cpu and args.no_parity):
