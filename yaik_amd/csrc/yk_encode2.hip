@@ -433,7 +433,11 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             // pixel: the tile's four lanes search the 16 possible values once per mode (4 each), the mode sums come from a 16-bin
             // histogram (sum over bins of count * minDiff / v), and only the winning mode's table is applied to the pixels.
             // Wave-uniform choice: taken when every live tile of the strip qualifies for this plane.
+#ifdef YK2_NO_SMALL
+            const bool smallWave = false;
+#else
             const bool smallWave = (__ballot(valid && (mx - mn) > 15) == 0ULL) && !(P.ablate & (4 | 32));
+#endif
             if (!smallWave) {
                 float rv[16];
 #pragma unroll
