@@ -70,3 +70,23 @@ def test_per_pixel_search_path_bit_exact(oracle_built, case):
             assert not bad, bad
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("rf", [0, 1, 2, 5, 9])
+def test_other_reject_factors_bit_exact(hip, oracle_built, rf):
+    """FittingQuadSmooth's rejectFactor is an argument of the operator (the shipped encoder always passes 3): the range tests on
+    D = S' - 256*cur and the second-difference early-out are parametrised by it."""
+    from oracle.pyoracle import PASSES, OracleEncoder
+    from tests.parity import cells_from_plane
+    for planes in (synth_planes(256, n_planes=3), edge_image(128, 128, "smooth", 3), edge_image(128, 128, "mixed", 3)):
+        ora = OracleEncoder(planes)
+        hip.set_image(planes)
+        hip.encode(rf, False, False)
+        for i, (sx, sy) in enumerate(PASSES):
+            cnt, bm, rgb = ora.fitting_quad_smooth(sx, sy, reject_factor=rf)
+            assert np.array_equal(hip.gradient_bitmap(i), bm), (rf, i)
+        assert np.array_equal(hip.coverage(), cells_from_plane(ora.state("smoothMap")))
+        for p in range(3):
+            defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
+            d2, n2, nn2 = hip.range_streams(p)
+            assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), (rf, p)
