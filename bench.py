@@ -2,12 +2,16 @@
 """bench.py — headline metric of BASELINE.json: Mpix/s of YAIK tile encode (alpha tile-reject + 7 gradient passes +
 8x8 4-bpp range quantiser of 3 planes) on an 8192x8192 RGBA frame of synthetic "YAIK-synth v1" data, inputs resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--mode3] [--no-cpu] [--no-parity]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--mode3] [--in-flight F] [--no-cpu] [--no-parity]
 
-One "step" = one pass of the hot path over one frame per GPU:
+One "step" = one pass of the hot path over one frame per GPU (F frames with --in-flight F):
     yk_alpha_reject -> yk_alpha_finish -> yk_encode_tiles (fused gradient+range kernel, then stream compaction)
-    and, for N > 1, ONE RCCL gather of the per-rank tile maps onto rank 0 (frame sharding, weak scaling).
-N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+    and, for N > 1, ONE RCCL gather of the per-rank tile maps onto rank 0 (frame sharding, weak scaling), double-buffered so
+    that the transfer of frame i rides under the kernels of frame i+1, and verified by checksums outside the timed region.
+Frames are queued back to back (no host synchronisation inside the timed loop); per-kernel times come from HIP events on the
+launch stream, averaged over the steps.  N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 prints ONE
+JSON line: the BASELINE metric + `roofline` (fused kernel, algorithmic bytes / event time; `traffic` from the committed PMC
+pass) + `cpu_baseline` (the CPU restatement on one host core of this box, with the measured restatement/reference ratio).
 """
 from __future__ import annotations
 
