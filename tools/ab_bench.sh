@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B two builds of the library on the same box with the whole bench step, alternating: tools/ab_bench.sh libA libB
+for i in 1 2; do
+  for v in "$1" "$2"; do
+    cp "$v" yaik_amd/libyaik_hip.so
+    echo "== $v"; timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-cpu --no-parity 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['other_kernels_ms'])"
+  done
+done
