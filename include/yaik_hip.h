@@ -94,6 +94,11 @@ int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
  *   mode3BitOnly : DynamicTileEncode's first argument (Stats.startMode = 3, :4412)
  *   wantDst      : also produce the decoded-value planes `dst` (:4448-4457); costs 12 B/pixel of writes */
 int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
+/* The whole frame with ONE launch: alpha reject (RGBA) + fused kernel + stream compaction captured as a hipGraph the first
+ * time and replayed afterwards (re-captured when the bound planes, the shape or the arguments change).  Same results as
+ * yk_alpha_reject + yk_alpha_finish(NULL) + yk_encode_tiles(.., wantDst 0); for batches of small frames, where the ~8 stream
+ * operations per frame cost more host time than the kernels take.  Whole images only (a stripe needs the host bbox step). */
+int yk_encode_frame(yk_ctx* c, int rejectFactor, int mode3BitOnly);
 
 /* gradient results (valid after yk_encode_tiles) -------------------------------------------------
  * swizzled 1-bit tile bitmap of pass p, byte-exact `pFillBitMap` (:3775-3777, bit rule :3801-3805,:4026;

@@ -164,3 +164,27 @@ def test_async_export_is_ordered_before_the_consumer_stream(hip):
         got_meta = meta.clone()
         assert got_meta.cpu().tolist() == [n] + [int(v) for v in sizes]
         assert torch.equal(got_blob, ref[:n])
+
+
+@pytest.mark.parametrize("size,npl", [(256, 4), (512, 3), (2048, 4)])
+def test_whole_frame_graph_launch_matches_the_stream_path(hip, oracle_built, size, npl):
+    """yk_encode_frame (alpha stage + fused kernel + compaction captured once, replayed as a hipGraph) == the three separate calls,
+    also when the graph is replayed on new pixel data and re-captured for another shape."""
+    from oracle.pyoracle import PASSES, OracleEncoder
+    from yaik_amd.synth import synth_planes
+    for seed in (12345, 777):
+        planes = synth_planes(size, n_planes=npl, seed=seed)
+        hip.set_image(planes)
+        for rep in range(2):                                              # capture, then replay
+            hip.encode_frame(3, False)
+        ora = OracleEncoder(planes)
+        if npl == 4:
+            mo = ora.mip_prefilter()
+            mh = hip.alpha_result()
+            assert np.array_equal(mh["bounds"], mo["bounds"]) and np.array_equal(mh["bitmap"], mo["bitmap"])
+        for i, (sx, sy) in enumerate(PASSES):
+            assert np.array_equal(hip.gradient_bitmap(i), ora.fitting_quad_smooth(sx, sy)[1]), i
+        for p in range(3):
+            defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
+            d2, n2, nn2 = hip.range_streams(p)
+            assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), p

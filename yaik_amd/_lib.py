@@ -48,6 +48,7 @@ SIGNATURES = {
     "yk_alpha_result": (C.c_int, [vp, vp, ip, ip, vp]),
     "yk_alpha_bitmap": (C.c_int, [vp, vp, sz, szp]),
     "yk_encode_tiles": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "yk_encode_frame": (C.c_int, [vp, C.c_int, C.c_int]),
     "yk_gradient_bitmap_bytes": (sz, [vp, C.c_int]),
     "yk_gradient_bitmap": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_gradient_bitmap_device": (vp, [vp, C.c_int]),

@@ -58,6 +58,7 @@ void yk_destroy(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
+    if (c->frameGraph) (void)hipGraphExecDestroy(c->frameGraph);
     if (c->evHandoff) (void)hipEventDestroy(c->evHandoff);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -283,6 +284,43 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;       // the oldest sets were overwritten
     c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
+    return YK_OK;
+}
+
+int yk_encode_frame(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
+    if (rejectFactor < 0 || rejectFactor > 64) return yk_fail(c, YK_ERR_BAD_ARG, "rejectFactor out of range");
+    if (c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "yk_encode_frame is the whole-image form (stripes need the bbox exchange between the stages)");
+    YK_HIP(c, hipSetDevice(c->device));
+    const unsigned long long key[12] = { (unsigned long long)(uintptr_t)c->plane[0], (unsigned long long)(uintptr_t)c->plane[1], (unsigned long long)(uintptr_t)c->plane[2],
+                                         (unsigned long long)(uintptr_t)c->plane[3], (unsigned long long)c->fullW, (unsigned long long)c->fullH, (unsigned long long)c->strideElems,
+                                         (unsigned long long)rejectFactor, (unsigned long long)(mode3BitOnly != 0), (unsigned long long)c->kernelVersion,
+                                         (unsigned long long)c->ablate, (unsigned long long)(uintptr_t)c->stream };
+    if (c->frameGraph && memcmp(key, c->frameGraphKey, sizeof key) != 0) { (void)hipGraphExecDestroy(c->frameGraph); c->frameGraph = nullptr; }
+    if (!c->frameGraph) {
+        hipGraph_t g = nullptr;
+        YK_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = YK_OK;
+        if (c->nPlanes == 4) rc = yk_launch_alpha(c);                       // bounds[0..4] are published by the bbox kernel (whole image)
+        if (rc == YK_OK) rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, 0);
+        if (rc == YK_OK) rc = yk_launch_pack(c);
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != YK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return yk_fail(c, YK_ERR_HIP, "hipStreamEndCapture", e);
+        const hipError_t e2 = hipGraphInstantiate(&c->frameGraph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { c->frameGraph = nullptr; return yk_fail(c, YK_ERR_HIP, "hipGraphInstantiate", e2); }
+        memcpy(c->frameGraphKey, key, sizeof key);
+    }
+    hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];                     // one interval for the whole frame (reported as "encode")
+    YK_HIP(c, hipEventRecord(ev[0], c->stream)); YK_HIP(c, hipEventRecord(ev[1], c->stream)); YK_HIP(c, hipEventRecord(ev[2], c->stream));
+    YK_HIP(c, hipGraphLaunch(c->frameGraph, c->stream));
+    YK_HIP(c, hipEventRecord(ev[3], c->stream)); YK_HIP(c, hipEventRecord(ev[4], c->stream));
+    c->evAlphaInCur = false; c->evHead++;
+    if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;
+    c->alphaDone = c->nPlanes == 4; c->alphaFinished = true;
+    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 

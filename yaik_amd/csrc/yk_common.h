@@ -94,6 +94,10 @@ struct yk_ctx {
     bool evAlphaInCur = false;
     float msEncode = 0, msAlpha = 0, msPack = 0;
     int ablate = 0;
+    // whole-frame graph (yk_encode_frame): the stream operations of alpha stage + fused kernel + compaction, captured once per
+    // (planes, shape, arguments) and replayed with one launch — for batches of small frames, where launches dominate
+    hipGraphExec_t frameGraph = nullptr;
+    unsigned long long frameGraphKey[12] = {};
     int kernelVersion = 2;              // 1 = yk_encode_kernel (lane = pixel row), 2 = yk_encode2_kernel (lane = 4x4 cell)
 };
 

@@ -113,6 +113,10 @@ class HipTileEncoder:
         _chk(self._h, L.yk_set_dst_fill(self._h, dst_fill))
         _chk(self._h, L.yk_encode_tiles(self._h, reject_factor, int(mode3bit_only), int(want_dst)))
 
+    def encode_frame(self, reject_factor: int = 3, mode3bit_only: bool = False):
+        """alpha reject + fused kernel + compaction as one replayed hipGraph launch (whole images; see yk_encode_frame)."""
+        _chk(self._h, lib().yk_encode_frame(self._h, reject_factor, int(mode3bit_only)))
+
     def synchronize(self):
         _chk(self._h, lib().yk_synchronize(self._h))
 
