@@ -119,3 +119,5 @@ def test_yaik_stream_round_trip_through_decoder_api(built, case):
     assert psnr > 30.0, psnr
     # (iii) API error convention: Decode without Pre fails, the sticky code reads once (YAIK_DECIMG_INVALIDCTX = 9) and resets
     assert np.frombuffer(got["yaik_error_convention"], np.int32).tolist() == [0, 9, 0]
+    # malformed streams: wrong magic -> YAIK_INVALID_HEADER (7); unknown tag / chunk past the end -> YAIK_INVALID_TAG_ID (20)
+    assert np.frombuffer(got["yaik_malformed"], np.int32).tolist() == [0, 7, 0, 20, 0, 20]

@@ -113,6 +113,25 @@ int main(int argc, char** argv) {
         const bool again = YAIK_DecodeImage(stream.data(), (u32)n, &di);
         int errs[3] = { again ? 1 : 0, (int)YAIK_GetErrorCode(), (int)YAIK_GetErrorCode() };
         blob("yaik_error_convention", errs, sizeof errs);
+        // malformed streams must be refused with the reference's codes, never crash: wrong magic, unknown chunk tag, chunk running past the end
+        int neg[6];
+        {
+            std::vector<u32> bad(stream); bad[0] ^= 0x01010101u;
+            neg[0] = YAIK_DecodeImagePre(lib, bad.data(), (u32)n, &di) ? 1 : 0; neg[1] = (int)YAIK_GetErrorCode();
+        }
+        {
+            std::vector<u32> bad(stream); bad[3] = 0x58585858u;           // first chunk tag (after the 12-byte file header) -> 'XXXX'
+            bool ok = YAIK_DecodeImagePre(lib, bad.data(), (u32)n, &di);
+            di.outputImage = outImg.data(); di.outputImageStride = di.width * bpp;
+            neg[2] = (ok && YAIK_DecodeImage(bad.data(), (u32)n, &di)) ? 1 : 0; neg[3] = (int)YAIK_GetErrorCode();
+        }
+        {
+            std::vector<u32> bad(stream); bad[4] = 0x7FFFFFF0u;           // first chunk length far beyond the stream
+            bool ok = YAIK_DecodeImagePre(lib, bad.data(), (u32)n, &di);
+            di.outputImage = outImg.data(); di.outputImageStride = di.width * bpp;
+            neg[4] = (ok && YAIK_DecodeImage(bad.data(), (u32)n, &di)) ? 1 : 0; neg[5] = (int)YAIK_GetErrorCode();
+        }
+        blob("yaik_malformed", neg, sizeof neg);
         YAIK_Release(lib);
     }
     fclose(gOut);
