@@ -36,6 +36,8 @@ def main() -> int:
     ap.add_argument("--mode3", action="store_true", help="3-bpp range modes only (DynamicTileEncode mode3BitOnly)")
     ap.add_argument("--in-flight", type=int, default=1, help="frames per GPU encoded concurrently on separate handles/streams (a step = that many "
                     "frames per GPU; 2 hides the HBM-bound alpha/pack kernels behind the VALU-bound fused kernel of the other frame)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU held by ONE handle and encoded with one launch per kernel (yk_encode_batch): "
+                    "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
                     "frames, where the ~8 stream operations per frame are what limits the rate; per-kernel times are then one interval")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -77,13 +79,24 @@ def main() -> int:
 
     W = args.size
     K = max(1, args.in_flight)
-    frames = [synth_planes_torch(W, n_planes=4, seed=12345 + rank * K + j, device=dev) for j in range(K)]   # frame f uses seed 12345+f
-    torch.cuda.synchronize()
-    planes = frames[0]
-
-    encs = [HipTileEncoder(dev_index) for _ in range(K)]
-    for e, f in zip(encs, frames):
-        e.set_image(f)
+    BF = max(0, args.batch)
+    if BF:
+        if world > 1 or K > 1 or args.graph:
+            print("--batch is a single-GPU, single-handle mode", file=sys.stderr)
+            return 2
+        batch = torch.stack([synth_planes_torch(W, n_planes=4, seed=12345 + j, device=dev) for j in range(BF)]).contiguous()
+        torch.cuda.synchronize()
+        planes = batch[0]
+        encs = [HipTileEncoder(dev_index)]
+        encs[0].set_batch(batch)
+        K = BF                                   # frames per step
+    else:
+        frames = [synth_planes_torch(W, n_planes=4, seed=12345 + rank * K + j, device=dev) for j in range(K)]   # frame f uses seed 12345+f
+        torch.cuda.synchronize()
+        planes = frames[0]
+        encs = [HipTileEncoder(dev_index) for _ in range(K)]
+        for e, f in zip(encs, frames):
+            e.set_image(f)
     enc = encs[0]
     # N > 1: every rank encodes its own frame; the ONE collective of the path, the gather of the packed tile maps onto rank 0,
     # is double-buffered so that the RCCL transfer of frame i rides under the encode kernels of frame i+1.
@@ -94,7 +107,9 @@ def main() -> int:
 
     def step():
         for e in encs:                         # no host synchronisation in here: K frames are in flight on K streams
-            if args.graph:
+            if BF:
+                e.encode_batch(3, args.mode3)
+            elif args.graph:
                 e.encode_frame(3, args.mode3)
             else:
                 e.alpha_reject()
@@ -143,7 +158,7 @@ def main() -> int:
             for e in encs:
                 k = e.kernel_ms()              # HIP events on the launch stream, averaged over the steps since the last query
                 for n in kms:
-                    kms[n] += k[n] * done / K
+                    kms[n] += k[n] * done / len(encs)
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -200,7 +215,7 @@ def main() -> int:
     # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh); only valid for the default workload
     traffic, traffic_src = None, None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-    if os.path.exists(tpath) and W == 8192 and not args.mode3 and K == 1:
+    if os.path.exists(tpath) and W == 8192 and not args.mode3 and K == 1 and not BF:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("kernel") == "yk_encode2_kernel":
@@ -209,7 +224,12 @@ def main() -> int:
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
                 "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (2 kernels)": round(kms["pack"], 4)}}
-    if args.graph:
+    if BF:
+        roofline["note"] = f"--batch {BF}: kernel times and algorithmic bytes are per launch = {BF} frames"
+        roofline["algorithmic_bytes"] = int(alg_bytes) * BF
+        roofline["achieved"] = round(alg_bytes * BF / (kms["encode"] * 1e-3) / 1e9, 1) if kms["encode"] > 0 else 0.0
+        roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
+    elif args.graph:
         roofline["note"] = "--graph: kernel_ms is the whole frame (alpha stage + fused kernel + compaction replayed as one hipGraph)"
     elif K > 1:
         roofline["note"] = f"{K} frames in flight: each kernel's duration includes the time it shares the chip with the other frame's kernels"
@@ -221,7 +241,7 @@ def main() -> int:
         "vs_baseline": None, "dtype": "u8/int32 (+f32 mode-selection sums)", "data": "synthetic (YAIK-synth v1, seed 12345+rank)",
         "config": {"workload": f"{W}x{W} RGBA frame per GPU, full encode: alpha reject bitmap + gradient tiles 16x16..4x4 + 8x8 "
                                f"{'3' if args.mode3 else '4'}-bpp range, inputs resident in HBM",
-                   "frames_per_step": world * K, "frames_in_flight_per_gpu": K, "launch": "hipGraph per frame" if args.graph else "stream operations",
+                   "frames_per_step": world * K, "frames_in_flight_per_gpu": K, "launch": ("one launch per kernel for the whole batch" if BF else "hipGraph per frame" if args.graph else "stream operations"),
                    "parallelism": f"frame-sharded x{world}, one RCCL gather of tile maps" if world > 1 else "single GPU"},
         "roofline": roofline,
     }

@@ -100,6 +100,17 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
  * operations per frame cost more host time than the kernels take.  Whole images only (a stripe needs the host bbox step). */
 int yk_encode_frame(yk_ctx* c, int rejectFactor, int mode3BitOnly);
 
+/* ---- batches of equally shaped images (new; BASELINE config 4: 256 x 2048x2048 frames) --------------------------------
+ * A frame of 2048x2048 is one round of waves: alone it cannot fill the chip.  A handle can hold nFrames images of one shape
+ * (yk_set_image for the shape, then yk_set_batch) whose planes lie at frame0Planes[p] + f * frameStrideElems; yk_encode_batch
+ * runs alpha reject + fused kernel + compaction over ALL frames with one launch per kernel (the grid simply spans
+ * nFrames x strips), with the same per-frame results as yk_encode_frame.  yk_select_frame chooses the frame every getter,
+ * yk_export_tile_maps, the corner streams and the 1-D path act on (default 0).  Whole images only, kernel version 2. */
+int yk_set_batch(yk_ctx* c, int nFrames);
+int yk_bind_device_batch(yk_ctx* c, const int32_t* const frame0Planes[4], int strideElems, size_t frameStrideElems);
+int yk_encode_batch(yk_ctx* c, int rejectFactor, int mode3BitOnly);
+int yk_select_frame(yk_ctx* c, int frame);
+
 /* gradient results (valid after yk_encode_tiles) -------------------------------------------------
  * swizzled 1-bit tile bitmap of pass p, byte-exact `pFillBitMap` (:3775-3777, bit rule :3801-3805,:4026;
  * size = HeaderGradientTile::getBitmapSwizzleSize/8, include/YAIK_private.h:278-286) */

@@ -188,3 +188,36 @@ def test_whole_frame_graph_launch_matches_the_stream_path(hip, oracle_built, siz
             defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
             d2, n2, nn2 = hip.range_streams(p)
             assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), p
+
+
+@pytest.mark.parametrize("size,npl,nf", [(256, 4, 5), (128, 3, 3), (2048, 4, 3)])
+def test_batch_launch_equals_per_frame_results(oracle_built, size, npl, nf):
+    """BASELINE config 4 (batches of equally shaped frames): yk_encode_batch spans all frames with one launch per kernel; every
+    frame's maps must equal the oracle's for that frame (seeds 12345+f), including the per-frame alpha bounds / reject bitmap."""
+    import torch
+    from oracle.pyoracle import PASSES, OracleEncoder
+    from yaik_amd.encoder import HipTileEncoder
+    from yaik_amd.synth import synth_planes
+    host = [synth_planes(size, n_planes=npl, seed=12345 + f) for f in range(nf)]
+    frames = torch.from_numpy(np.stack(host)).cuda()
+    e = HipTileEncoder(0)
+    try:
+        e.set_batch(frames)
+        for rep in range(2):                                              # the second run checks that the scan state was left clean
+            e.encode_batch(3, False)
+        for f in range(nf):
+            e.select_frame(f)
+            ora = OracleEncoder(host[f])
+            if npl == 4:
+                mo, mh = ora.mip_prefilter(), e.alpha_result()
+                assert np.array_equal(mh["bounds"], mo["bounds"]) and np.array_equal(mh["bitmap"], mo["bitmap"]), f
+            for i, (sx, sy) in enumerate(PASSES):
+                cnt, bm, rgb = ora.fitting_quad_smooth(sx, sy)
+                assert np.array_equal(e.gradient_bitmap(i), bm), (f, i)
+                assert np.array_equal(e.gradient_corners(i), rgb), (f, i)
+            for p in range(3):
+                defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
+                d2, n2, nn2 = e.range_streams(p)
+                assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), (f, p)
+    finally:
+        e.close()

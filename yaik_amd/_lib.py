@@ -49,6 +49,10 @@ SIGNATURES = {
     "yk_alpha_bitmap": (C.c_int, [vp, vp, sz, szp]),
     "yk_encode_tiles": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "yk_encode_frame": (C.c_int, [vp, C.c_int, C.c_int]),
+    "yk_set_batch": (C.c_int, [vp, C.c_int]),
+    "yk_bind_device_batch": (C.c_int, [vp, C.POINTER(vp), C.c_int, sz]),
+    "yk_encode_batch": (C.c_int, [vp, C.c_int, C.c_int]),
+    "yk_select_frame": (C.c_int, [vp, C.c_int]),
     "yk_gradient_bitmap_bytes": (sz, [vp, C.c_int]),
     "yk_gradient_bitmap": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_gradient_bitmap_device": (vp, [vp, C.c_int]),

@@ -13,16 +13,71 @@ int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e) {
     return code;
 }
 
+void yk_rebase(yk_ctx* c, int f) {
+    const YkFrameStrides& fs = c->fs; auto& B = c->B;
+    c->curFrame = f;
+    for (int i = 0; i < 4; i++) c->plane[i] = B.plane[i] ? B.plane[i] + (size_t)f * fs.plane : nullptr;
+    c->keep = B.keep + (size_t)f * fs.keep; c->bounds = B.bounds + (size_t)f * 16;
+    for (int i = 0; i < 7; i++) c->bitmap[i] = B.bitmap[i] + (size_t)f * fs.bitmap[i];
+    c->coverage = B.coverage + (size_t)f * fs.coverage; c->tileDef = B.tileDef + (size_t)f * fs.tileDef;
+    c->tileCount = B.tileCount + (size_t)f * fs.tileCount; c->slots = B.slots + (size_t)f * fs.slots;
+    c->blockSums = B.blockSums + (size_t)f * fs.blockN; c->blockCnt = B.blockCnt + (size_t)f * fs.blockN;
+    c->totals = B.totals + (size_t)f * 8; c->defsOut = B.defsOut + (size_t)f * fs.defsOut; c->nibOut = B.nibOut + (size_t)f * fs.nibOut;
+}
+
 static void yk_free_image(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(c->keep); F(c->bounds);
-    for (int i = 0; i < 7; i++) F(c->bitmap[i]);
-    F(c->coverage); F(c->tileDef); F(c->tileCount); F(c->slots);
+    auto& B = c->B;
+    F(B.keep); F(B.bounds);
+    for (int i = 0; i < 7; i++) F(B.bitmap[i]);
+    F(B.coverage); F(B.tileDef); F(B.tileCount); F(B.slots);
     for (int i = 0; i < 3; i++) F(c->dst[i]);
-    F(c->blockSums); F(c->blockCnt); F(c->totals); F(c->exportSizes); F(c->defsOut); F(c->nibOut);
+    F(B.blockSums); F(B.blockCnt); F(B.totals); F(c->exportSizes); F(B.defsOut); F(B.nibOut);
+    c->keep = nullptr; c->bounds = nullptr; for (int i = 0; i < 7; i++) c->bitmap[i] = nullptr;
+    c->coverage = nullptr; c->tileDef = nullptr; c->tileCount = nullptr; c->slots = nullptr;
+    c->blockSums = nullptr; c->blockCnt = nullptr; c->totals = nullptr; c->defsOut = nullptr; c->nibOut = nullptr;
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
+    if (c->frameGraph) { (void)hipGraphExecDestroy(c->frameGraph); c->frameGraph = nullptr; }
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+}
+
+// allocates every per-image array c->nFrames times (geometry fields are set) and points the handle at frame 0
+static int yk_alloc_image(yk_ctx* c) {
+    const size_t F = (size_t)c->nFrames;
+    const size_t T8 = (size_t)c->tilesW * c->tilesH, MT = (size_t)c->mtW * c->mtH;
+    auto& B = c->B; YkFrameStrides& fs = c->fs;
+    auto up = [](size_t n, size_t a) { return (n + a - 1) / a * a; };
+    fs.keep = up(MT + 4, 16);                                   // read as 4-byte words by yk_alpha_bbox_kernel
+    YK_HIP(c, hipMalloc(&B.keep, fs.keep * F + 16));
+    YK_HIP(c, hipMalloc(&B.bounds, 16 * sizeof(int32_t) * F));
+    static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    for (int i = 0; i < 7; i++) {
+        const int bx = (sh[i][0] == 2) ? 32 : 64, by = (sh[i][1] == 2) ? 32 : 64;
+        const size_t bits = (size_t)((c->fullW + bx - 1) / bx) * ((c->h + by - 1) / by) * ((bx >> sh[i][0]) * (by >> sh[i][1]));
+        c->bitmapBytes[i] = bits >> 3;
+        fs.bitmap[i] = up(c->bitmapBytes[i] + 4, 16);           // + the padding word pass 0 may touch
+        YK_HIP(c, hipMalloc(&B.bitmap[i], fs.bitmap[i] * F + 16));
+    }
+    fs.coverage = up(MT, 8); fs.tileDef = 3 * T8; fs.tileCount = 3 * T8; fs.slots = 3 * T8 * YK_SLOT;
+    YK_HIP(c, hipMalloc(&B.coverage, fs.coverage * F * sizeof(uint16_t)));
+    YK_HIP(c, hipMalloc(&B.tileDef, fs.tileDef * F * sizeof(uint16_t) + 16));
+    YK_HIP(c, hipMalloc(&B.tileCount, fs.tileCount * F + 16));
+    YK_HIP(c, hipMalloc(&B.slots, fs.slots * F + 16));
+    c->nScanBlocks = (int)((T8 + 1023) / 1024);
+    fs.blockN = (size_t)c->nScanBlocks * 2;
+    YK_HIP(c, hipMalloc(&B.blockSums, fs.blockN * F * sizeof(uint32_t)));
+    YK_HIP(c, hipMalloc(&B.blockCnt, fs.blockN * F * sizeof(uint32_t)));
+    YK_HIP(c, hipMemsetAsync(B.blockCnt, 0, fs.blockN * F * sizeof(uint32_t), c->stream));   // kept zero between frames by the scan
+    YK_HIP(c, hipMalloc(&B.totals, 8 * sizeof(uint32_t) * F));
+    fs.defsOut = 3 * T8;
+    YK_HIP(c, hipMalloc(&B.defsOut, fs.defsOut * F * sizeof(uint16_t) + 16));
+    c->nibStride = T8 * YK_SLOT + 64;
+    fs.nibOut = 3 * c->nibStride;
+    YK_HIP(c, hipMalloc(&B.nibOut, fs.nibOut * F + 16));
+    c->dstValid = false;
+    yk_rebase(c, 0);
+    return YK_OK;
 }
 
 extern "C" {
@@ -95,29 +150,37 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
     yk_free_image(c);
     c->fullW = fullW; c->fullH = fullH; c->nPlanes = nPlanes; c->y0 = y0; c->h = h; c->halo = haloRows;
     c->tilesW = fullW / 8; c->tilesH = h / 8; c->mtW = (fullW + 15) / 16; c->mtH = (h + 15) / 16;
-    const size_t T8 = (size_t)c->tilesW * c->tilesH, MT = (size_t)c->mtW * c->mtH;
-    YK_HIP(c, hipMalloc(&c->keep, MT + 16));             // read as 4-byte words by yk_alpha_bbox_kernel
-    YK_HIP(c, hipMalloc(&c->bounds, 16 * sizeof(int32_t)));
-    static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
-    for (int i = 0; i < 7; i++) {
-        const int bx = (sh[i][0] == 2) ? 32 : 64, by = (sh[i][1] == 2) ? 32 : 64;
-        const size_t bits = (size_t)((fullW + bx - 1) / bx) * ((h + by - 1) / by) * ((bx >> sh[i][0]) * (by >> sh[i][1]));
-        c->bitmapBytes[i] = bits >> 3;
-        YK_HIP(c, hipMalloc(&c->bitmap[i], c->bitmapBytes[i] + 16));
+    c->nFrames = 1; c->fs.plane = 0;
+    for (int i = 0; i < 4; i++) { c->B.plane[i] = nullptr; c->plane[i] = nullptr; }
+    return yk_alloc_image(c);
+}
+
+int yk_set_batch(yk_ctx* c, int nFrames) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->tileCount) return yk_fail(c, YK_ERR_STATE, "yk_set_image first");
+    if (nFrames < 1 || nFrames > 1024) return yk_fail(c, YK_ERR_BAD_ARG, "nFrames must be 1..1024");
+    if (c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "batches hold whole images, not stripes");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (nFrames != c->nFrames) {
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        const int32_t* keepPlanes[4] = { c->B.plane[0], c->B.plane[1], c->B.plane[2], c->B.plane[3] };
+        const unsigned long long planeStride = c->fs.plane;
+        yk_free_image(c);
+        c->nFrames = nFrames;
+        int rc = yk_alloc_image(c); if (rc) return rc;
+        for (int i = 0; i < 4; i++) c->B.plane[i] = keepPlanes[i];
+        c->fs.plane = planeStride;
+        yk_rebase(c, 0);
     }
-    YK_HIP(c, hipMalloc(&c->coverage, MT * sizeof(uint16_t)));
-    YK_HIP(c, hipMalloc(&c->tileDef, 3 * T8 * sizeof(uint16_t)));
-    YK_HIP(c, hipMalloc(&c->tileCount, 3 * T8));
-    YK_HIP(c, hipMalloc(&c->slots, 3 * T8 * YK_SLOT));
-    c->nScanBlocks = (int)((T8 + 1023) / 1024);
-    YK_HIP(c, hipMalloc(&c->blockSums, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t)));
-    YK_HIP(c, hipMalloc(&c->blockCnt, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t)));
-    YK_HIP(c, hipMemsetAsync(c->blockCnt, 0, (size_t)c->nScanBlocks * 2 * sizeof(uint32_t), c->stream));   // kept zero between frames by the scan
-    YK_HIP(c, hipMalloc(&c->totals, 6 * sizeof(uint32_t)));
-    YK_HIP(c, hipMalloc(&c->defsOut, 3 * T8 * sizeof(uint16_t)));
-    c->nibStride = T8 * YK_SLOT + 64;
-    YK_HIP(c, hipMalloc(&c->nibOut, 3 * c->nibStride));
-    c->dstValid = false;
+    return YK_OK;
+}
+
+int yk_select_frame(yk_ctx* c, int frame) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->tileCount) return yk_fail(c, YK_ERR_STATE, "yk_set_image first");
+    if (frame < 0 || frame >= c->nFrames) return yk_fail(c, YK_ERR_BAD_ARG, "frame out of range");
+    yk_rebase(c, frame);
+    c->cornersReady = false; c->r1Ready = false;
     return YK_OK;
 }
 
@@ -138,11 +201,14 @@ int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideEl
         YK_HIP(c, hipMalloc(&c->ownedPlanes, planeBytes * c->nPlanes));
         c->ownedPlanesBytes = planeBytes * c->nPlanes;
     }
+    if (c->nFrames != 1) return yk_fail(c, YK_ERR_STATE, "batches bind device planes (yk_bind_device_batch)");
+    for (int i = 0; i < 4; i++) c->B.plane[i] = nullptr;
     for (int i = 0; i < c->nPlanes; i++) {
         int32_t* d = c->ownedPlanes + (size_t)i * rows * c->fullW;
         YK_HIP(c, hipMemcpy2DAsync(d, (size_t)c->fullW * 4, hostPlanes[i], (size_t)strideElems * 4, (size_t)c->fullW * 4, rows, hipMemcpyHostToDevice, c->stream));
-        c->plane[i] = d;
+        c->B.plane[i] = d;
     }
+    c->fs.plane = 0; yk_rebase(c, 0);
     c->strideElems = c->fullW;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
     return YK_OK;
@@ -150,10 +216,27 @@ int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideEl
 
 int yk_bind_device_planes(yk_ctx* c, const int32_t* const devPlanes[4], int strideElems) {
     int rc = yk_check_planes(c, devPlanes, strideElems); if (rc) return rc;
+    if (c->nFrames != 1) return yk_fail(c, YK_ERR_STATE, "batches bind device planes with yk_bind_device_batch");
+    for (int i = 0; i < 4; i++) c->B.plane[i] = nullptr;
     for (int i = 0; i < c->nPlanes; i++) {
         if (((uintptr_t)devPlanes[i]) & 15) return yk_fail(c, YK_ERR_BAD_ARG, "device planes must be 16-byte aligned");
-        c->plane[i] = devPlanes[i];
+        c->B.plane[i] = devPlanes[i];
     }
+    c->fs.plane = 0; yk_rebase(c, 0);
+    c->strideElems = strideElems;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
+    return YK_OK;
+}
+
+int yk_bind_device_batch(yk_ctx* c, const int32_t* const frame0Planes[4], int strideElems, size_t frameStrideElems) {
+    int rc = yk_check_planes(c, frame0Planes, strideElems); if (rc) return rc;
+    if (c->nFrames > 1 && (frameStrideElems < (size_t)strideElems * c->fullH || (frameStrideElems & 3))) return yk_fail(c, YK_ERR_BAD_ARG, "frame stride must cover a plane and be a multiple of 4 elements");
+    for (int i = 0; i < 4; i++) c->B.plane[i] = nullptr;
+    for (int i = 0; i < c->nPlanes; i++) {
+        if (((uintptr_t)frame0Planes[i]) & 15) return yk_fail(c, YK_ERR_BAD_ARG, "device planes must be 16-byte aligned");
+        c->B.plane[i] = frame0Planes[i];
+    }
+    c->fs.plane = frameStrideElems; yk_rebase(c, c->curFrame < c->nFrames ? c->curFrame : 0);
     c->strideElems = strideElems;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
     return YK_OK;
@@ -284,6 +367,32 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;       // the oldest sets were overwritten
     c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
+    return YK_OK;
+}
+
+int yk_encode_batch(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->B.plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
+    if (rejectFactor < 0 || rejectFactor > 64) return yk_fail(c, YK_ERR_BAD_ARG, "rejectFactor out of range");
+    if (c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "batches hold whole images");
+    if (c->kernelVersion != 2) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
+    if (c->nFrames > 1 && c->fs.plane == 0) return yk_fail(c, YK_ERR_STATE, "yk_bind_device_batch first");
+    YK_HIP(c, hipSetDevice(c->device));
+    hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];
+    YK_HIP(c, hipEventRecord(ev[0], c->stream));
+    int rc = YK_OK;
+    if (c->nPlanes == 4) rc = yk_launch_alpha(c, true);                     // every frame's bbox kernel publishes its own bounds[0..4]
+    if (rc) return rc;
+    YK_HIP(c, hipEventRecord(ev[1], c->stream));
+    YK_HIP(c, hipEventRecord(ev[2], c->stream));
+    rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, 0, true); if (rc) return rc;
+    YK_HIP(c, hipEventRecord(ev[3], c->stream));
+    rc = yk_launch_pack(c, true); if (rc) return rc;
+    YK_HIP(c, hipEventRecord(ev[4], c->stream));
+    c->evAlphaInCur = false; c->evHead++;
+    if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;
+    c->alphaDone = c->nPlanes == 4; c->alphaFinished = true;
+    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 

@@ -12,6 +12,12 @@
 #define YK_EV_RING  64
 #define YK_SLOT     32      // bytes of nibble slot per 8x8 tile-plane (64 nibbles)
 
+// Batches: one handle can hold nFrames images of one shape; every per-image array is allocated nFrames times back to back and
+// the batch kernels address frame f at base + f * stride (elements of the array's own type).
+struct YkFrameStrides {
+    unsigned long long plane, keep, bitmap[7], coverage, tileDef, tileCount, slots, blockN, defsOut, nibOut;   // bounds: 16 ints, totals: 8 u32
+};
+
 struct YkEncodeParams {
     const int32_t* plane[4];
     int strideElems;
@@ -34,6 +40,8 @@ struct YkEncodeParams {
     int32_t*  dst[3];
     int tilesW, tilesH, mtW, mtH;
     int xBB64, yBB64, xBB32, yBB32;
+    int nFrames;            // 1 unless launched by yk_encode_batch
+    YkFrameStrides fs;
 };
 
 struct yk_ctx {
@@ -45,6 +53,13 @@ struct yk_ctx {
     // geometry
     int fullW = 0, fullH = 0, nPlanes = 0, y0 = 0, h = 0, halo = 0;
     int tilesW = 0, tilesH = 0, mtW = 0, mtH = 0;
+    // batch: the pointers below are those of frame `curFrame`; B holds the allocations (frame 0), fs the per-frame strides
+    int nFrames = 1, curFrame = 0;
+    YkFrameStrides fs = {};
+    struct Bases {
+        const int32_t* plane[4]; uint8_t* keep; int32_t* bounds; uint8_t* bitmap[7]; uint16_t* coverage; uint16_t* tileDef; uint8_t* tileCount;
+        uint8_t* slots; uint32_t* blockSums; uint32_t* blockCnt; uint32_t* totals; uint16_t* defsOut; uint8_t* nibOut;
+    } B = {};
     // input
     const int32_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};
     int strideElems = 0;
@@ -105,9 +120,10 @@ int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
 #define YK_HIP(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return yk_fail((c), YK_ERR_HIP, #call, _e); } while (0)
 
 // launchers implemented in the kernel TUs
-int yk_launch_alpha(yk_ctx* c);
+void yk_rebase(yk_ctx* c, int frame);                    // point the working pointers at `frame`
+int yk_launch_alpha(yk_ctx* c, bool batch = false);
 int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
-int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst);
-int yk_launch_pack(yk_ctx* c);
+int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch = false);
+int yk_launch_pack(yk_ctx* c, bool batch = false);
 int yk_launch_corners(yk_ctx* c);
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P);

@@ -27,15 +27,20 @@ __constant__ float c_curve[6][16] = YK_CURVE_TABLE;
 // tile row; a non-zero group raises the tile's flag with an idempotent byte store into the pre-zeroed map, so the
 // streaming path has no atomics.  The bounding box is derived from the flags afterwards (yk_alpha_bbox_kernel).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha, int strideElems, int w, int h,
-                                                       uint8_t* __restrict__ keep, int mtW, int32_t* __restrict__ bounds) {
-    // accumulators of the bounding-box kernel that follows on the stream: {x0,y0,x1,y1} = empty, done-counter = 0
-    if (blockIdx.x == 0 && threadIdx.x < 5) bounds[8 + threadIdx.x] = threadIdx.x < 2 ? 9999999 : (threadIdx.x < 4 ? -1 : 0);
+__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h,
+                                                       uint8_t* __restrict__ keep0, int mtW, int32_t* __restrict__ bounds,
+                                                       int nFrames, unsigned long long planeStride, unsigned long long keepStride) {
+    // accumulators of the bounding-box kernel that follows on the stream: {x0,y0,x1,y1} = empty, done-counter = 0 (one set per frame)
+    for (int f = blockIdx.x; f < nFrames; f += gridDim.x)
+        if (threadIdx.x < 5) bounds[(size_t)f * 16 + 8 + threadIdx.x] = threadIdx.x < 2 ? 9999999 : (threadIdx.x < 4 ? -1 : 0);
     const int lane = threadIdx.x & 63;
     const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
     const int nSeg = (vecPerRow + 1023) >> 10;
     const int nUnits = nSeg * h;
-    for (int u = blockIdx.x; u < nUnits; u += gridDim.x) {
+    for (long long uu = blockIdx.x; uu < (long long)nUnits * nFrames; uu += gridDim.x) {
+        const int f = (int)(uu / nUnits), u = (int)(uu - (long long)f * nUnits);
+        const int32_t* alpha = alpha0 + (size_t)f * planeStride;
+        uint8_t* keep = keep0 + (size_t)f * keepStride;
         const int y = u / nSeg, seg = u - y * nSeg;
         const int32_t* row = alpha + (size_t)y * strideElems;
         int4 a[4];
@@ -59,8 +64,10 @@ __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict
 // publishes the whole-image form: bounds[0..3] = the box, bounds[4] = "bbox == whole image -> every reject discarded"
 // (EncoderContext.cpp:1294, :1400-1403); a stripe caller overrides these five ints with the host-combined box.
 __global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint32_t* __restrict__ keep4, int mtW, int mtH, int y0, int32_t* __restrict__ bounds,
-                                                            int fullW, int fullH) {
+                                                            int fullW, int fullH, unsigned long long keepStrideWords) {
     __shared__ int s_red[4][4];
+    keep4 += (size_t)blockIdx.y * keepStrideWords;               // blockIdx.y = frame of a batch
+    bounds += (size_t)blockIdx.y * 16;
     int32_t* bbox = bounds + 8;
     int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
     const int n = mtW * mtH, n4 = (n + 3) >> 2;                  // four 1-byte flags per load (the map is padded to a multiple of 4)
@@ -537,8 +544,11 @@ __global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restric
 // planes, and the words of the nibble streams that two blocks share: yk_pack_kernel ORs into those, so they are cleared here;
 // every other word of a stream is written whole.
 __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
-                                                        uint32_t* __restrict__ totals, uint32_t* __restrict__ nib, size_t strideWords) {
+                                                        uint32_t* __restrict__ totals, uint32_t* __restrict__ nib, size_t strideWords,
+                                                        unsigned long long blockNStride, unsigned long long nibFrameWords) {
     __shared__ uint32_t s_tmp[32];
+    blockCnt += (size_t)blockIdx.x * blockNStride; blockSums += (size_t)blockIdx.x * blockNStride;     // blockIdx.x = frame of a batch
+    totals += (size_t)blockIdx.x * 8; nib += (size_t)blockIdx.x * nibFrameWords;
     uint32_t baseN = 0, baseD = 0;
     for (int start = 0; start < nBlocks; start += 1024) {
         const int i = start + threadIdx.x;
@@ -567,9 +577,14 @@ __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ b
 // into place in an LDS image of the block's piece of the stream, and that piece goes out as one contiguous run of words.
 __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
                                                        const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
-                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords) {
+                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords, YkFrameStrides fs) {
     __shared__ uint32_t s_tmp[32];
     __shared__ uint32_t s_out[YK_SCAN_TILE * 8 + 8];
+    {   // blockIdx.z = frame of a batch
+        const size_t f = blockIdx.z;
+        tileCount += f * fs.tileCount; tileDef += f * fs.tileDef; slots += f * fs.slots; blockSums += f * fs.blockN;
+        defsOut += f * fs.defsOut; nibOut += f * (fs.nibOut / 4);
+    }
     const int p = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
     const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
@@ -621,16 +636,20 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
-int yk_launch_alpha(yk_ctx* c) {
+int yk_launch_alpha(yk_ctx* c, bool batch) {
+    const int F = batch ? c->nFrames : 1;
+    uint8_t* keep = batch ? c->B.keep : c->keep;
+    int32_t* bounds = batch ? c->B.bounds : c->bounds;
+    const int32_t* alpha = batch ? c->B.plane[3] : c->plane[3];
     const size_t nFlags = ((size_t)c->mtW * c->mtH + 3) & ~(size_t)3;
-    YK_HIP(c, hipMemsetAsync(c->keep, 0, nFlags, c->stream));
-    const int nUnits = ((c->fullW / 4 + 1023) / 1024) * c->h;
-    hipLaunchKernelGGL(yk_alpha_kernel, dim3(nUnits < 4096 ? nUnits : 4096), dim3(256), 0, c->stream, c->plane[3], c->strideElems, c->fullW, c->h,
-                       c->keep, c->mtW, c->bounds);
+    YK_HIP(c, hipMemsetAsync(keep, 0, F > 1 ? (size_t)c->fs.keep * F : nFlags, c->stream));
+    const long long nUnits = (long long)((c->fullW / 4 + 1023) / 1024) * c->h * F;
+    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < 4096 ? nUnits : 4096)), dim3(256), 0, c->stream, alpha, c->strideElems, c->fullW, c->h,
+                       keep, c->mtW, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep);
     YK_HIP(c, hipGetLastError());
     const int nb = (int)((nFlags / 4 + 1023) / 1024);
-    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 128 ? nb : 128), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->keep), c->mtW, c->mtH,
-                       c->y0, c->bounds, c->fullW, c->fullH);
+    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 128 ? nb : 128, F), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(keep), c->mtW, c->mtH,
+                       c->y0, bounds, c->fullW, c->fullH, (unsigned long long)(c->fs.keep / 4));
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
@@ -645,34 +664,39 @@ int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox) {
     return YK_OK;
 }
 
-int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) {
+int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch) {
     YkEncodeParams P;
-    for (int i = 0; i < 4; i++) P.plane[i] = c->plane[i];
+    for (int i = 0; i < 4; i++) P.plane[i] = batch ? c->B.plane[i] : c->plane[i];
     P.strideElems = c->strideElems; P.w = c->fullW; P.h = c->h; P.hAvail = c->h + c->halo; P.y0 = c->y0; P.fullH = c->fullH;
     P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst; P.ablate = c->ablate;
-    P.keep = (c->nPlanes == 4) ? c->keep : nullptr;
-    P.bounds = (c->nPlanes == 4) ? c->bounds : nullptr;
-    for (int i = 0; i < 7; i++) P.bitmap[i] = c->bitmap[i];
-    P.coverage = c->coverage; P.tileDef = c->tileDef; P.tileCount = c->tileCount; P.slots = c->slots;
-    P.blockCnt = c->kernelVersion == 2 ? c->blockCnt : nullptr;
+    P.keep = (c->nPlanes == 4) ? (batch ? c->B.keep : c->keep) : nullptr;
+    P.bounds = (c->nPlanes == 4) ? (batch ? c->B.bounds : c->bounds) : nullptr;
+    for (int i = 0; i < 7; i++) P.bitmap[i] = batch ? c->B.bitmap[i] : c->bitmap[i];
+    P.coverage = batch ? c->B.coverage : c->coverage; P.tileDef = batch ? c->B.tileDef : c->tileDef;
+    P.tileCount = batch ? c->B.tileCount : c->tileCount; P.slots = batch ? c->B.slots : c->slots;
+    P.blockCnt = c->kernelVersion == 2 ? (batch ? c->B.blockCnt : c->blockCnt) : nullptr;
     for (int i = 0; i < 3; i++) P.dst[i] = c->dst[i];
     P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
     P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
+    P.nFrames = batch ? c->nFrames : 1; P.fs = c->fs;
     if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
+    if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
     dim3 grid(P.xBB64, P.yBB64);
     hipLaunchKernelGGL(yk_encode_kernel, grid, dim3(256), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
 
-int yk_launch_pack(yk_ctx* c) {
+int yk_launch_pack(yk_ctx* c, bool batch) {
     const size_t T8 = (size_t)c->tilesW * c->tilesH;
-    const int nb = c->nScanBlocks;
+    const int nb = c->nScanBlocks, F = batch ? c->nFrames : 1;
+    uint32_t* blockCnt = batch ? c->B.blockCnt : c->blockCnt; uint32_t* blockSums = batch ? c->B.blockSums : c->blockSums;
+    uint32_t* totals = batch ? c->B.totals : c->totals; uint8_t* nibOut = batch ? c->B.nibOut : c->nibOut;
     if (c->kernelVersion != 2) hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockCnt);
-    hipLaunchKernelGGL(yk_scan2_kernel, dim3(1), dim3(1024), 0, c->stream, c->blockCnt, c->blockSums, nb, c->totals,
-                       reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
-    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3), dim3(1024), 0, c->stream, c->tileCount, c->tileDef, c->slots, T8, c->blockSums, nb,
-                       c->defsOut, reinterpret_cast<uint32_t*>(c->nibOut), c->nibStride / 4);
+    hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals,
+                       reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, (unsigned long long)c->fs.blockN, (unsigned long long)(c->fs.nibOut / 4));
+    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3, F), dim3(1024), 0, c->stream, batch ? c->B.tileCount : c->tileCount, batch ? c->B.tileDef : c->tileDef,
+                       batch ? c->B.slots : c->slots, T8, blockSums, nb, batch ? c->B.defsOut : c->defsOut, reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, c->fs);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }

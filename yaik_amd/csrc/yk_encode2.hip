@@ -167,12 +167,24 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     // halo column of a block and the halo row of a strip are lines a neighbour streams through the same L2 at about the same
     // time instead of a second fabric fetch, while every XCD still samples the whole image (whole bands per XCD would leave
     // the cheapest band's XCD idle).
-    const int nB = P.xBB64 * P.yBB64;
+    const int nBf = P.xBB64 * P.yBB64, nB = nBf * P.nFrames;             // blocks per frame / of the whole batch
     const int slot = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
     const int grp = slot / (YK2_RUN * 4);
     const int unit = (grp * 8 + ((xcd + grp) & 7)) * (YK2_RUN * 4) + (slot - grp * (YK2_RUN * 4));
-    const int L = unit >> 2, wave = unit & 3;                                // block (row-major) and strip inside the block
+    int L = unit >> 2; const int wave = unit & 3;                            // block (row-major, frames back to back) and strip inside the block
     if (L >= nB) return;
+    // batch: per-image pointers of this block's frame (wave-uniform scalars; the kernel argument itself is never copied)
+    size_t fr = 0;
+    if (P.nFrames > 1) { fr = (size_t)(L / nBf); L -= (int)fr * nBf; }
+    const int32_t* const pl0 = P.plane[0] + fr * P.fs.plane; const int32_t* const pl1 = P.plane[1] + fr * P.fs.plane; const int32_t* const pl2 = P.plane[2] + fr * P.fs.plane;
+    const uint8_t* const keepP = P.keep ? P.keep + fr * P.fs.keep : nullptr;
+    const int32_t* const boundsP = P.bounds ? P.bounds + fr * 16 : nullptr;
+    uint16_t* const coverageP = P.coverage + fr * P.fs.coverage;
+    uint16_t* const tileDefP = P.tileDef + fr * P.fs.tileDef;
+    uint8_t* const tileCountP = P.tileCount + fr * P.fs.tileCount;
+    uint8_t* const slotsP = P.slots + fr * P.fs.slots;
+    uint32_t* const blockCntP = P.blockCnt + fr * P.fs.blockN;
+#define YK2_BM(i) (P.bitmap[i] + fr * P.fs.bitmap[i])
     const int BY = L / P.xBB64, BX = L - BY * P.xBB64;
     const int w = P.w, h = P.h;
 
@@ -191,12 +203,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const int gy = min(gyS + r0 + 4 * k, P.hAvail - 1);
             if (inX) {
                 const size_t off = (size_t)gy * P.strideElems + gx;
-                R[k] = *reinterpret_cast<const int4*>(P.plane[0] + off);
-                G[k] = *reinterpret_cast<const int4*>(P.plane[1] + off);
-                B[k] = *reinterpret_cast<const int4*>(P.plane[2] + off);
+                R[k] = *reinterpret_cast<const int4*>(pl0 + off);
+                G[k] = *reinterpret_cast<const int4*>(pl1 + off);
+                B[k] = *reinterpret_cast<const int4*>(pl2 + off);
             } else {
                 const size_t off = (size_t)gy * P.strideElems + (w - 1);
-                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                const int r = pl0[off], gg = pl1[off], b = pl2[off];
                 R[k] = make_int4(r, r, r, r); G[k] = make_int4(gg, gg, gg, gg); B[k] = make_int4(b, b, b, b);
             }
         }
@@ -205,12 +217,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const int gy = min(gyS + 16, P.hAvail - 1);
             if (inX) {
                 const size_t off = (size_t)gy * P.strideElems + gx;
-                Rb = *reinterpret_cast<const int4*>(P.plane[0] + off);
-                Gb = *reinterpret_cast<const int4*>(P.plane[1] + off);
-                Bb = *reinterpret_cast<const int4*>(P.plane[2] + off);
+                Rb = *reinterpret_cast<const int4*>(pl0 + off);
+                Gb = *reinterpret_cast<const int4*>(pl1 + off);
+                Bb = *reinterpret_cast<const int4*>(pl2 + off);
             } else {
                 const size_t off = (size_t)gy * P.strideElems + (w - 1);
-                const int r = P.plane[0][off], gg = P.plane[1][off], b = P.plane[2][off];
+                const int r = pl0[off], gg = pl1[off], b = pl2[off];
                 Rb = make_int4(r, r, r, r); Gb = make_int4(gg, gg, gg, gg); Bb = make_int4(b, b, b, b);
             }
         }
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         if (hr >= 0 && hr < 17) {
             const int gy = min(gyS + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
             const size_t off = (size_t)gy * P.strideElems + gxh;
-            hcol = (uint32_t)P.plane[0][off] | ((uint32_t)P.plane[1][off] << 8) | ((uint32_t)P.plane[2][off] << 16);
+            hcol = (uint32_t)pl0[off] | ((uint32_t)pl1[off] << 8) | ((uint32_t)pl2[off] << 16);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     }
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
-    if (cell == 0 && mtIn) P.coverage[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
+    if (cell == 0 && mtIn) coverageP[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
 
     // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
     // strip's tiles into whole bytes of the block's words except 16x16 (4 bits per strip), which is OR-ed into a pre-zeroed map.
@@ -292,28 +304,28 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     if (lane == 0) {
         const int i64 = BY * P.xBB64 + BX;
         const uint32_t nib = (s_bm[0] >> (4 * wave)) & 0xFu;
-        if (nib) atomicOr(reinterpret_cast<uint32_t*>(P.bitmap[0]) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave));
-        P.bitmap[1][i64 * 4 + wave] = (uint8_t)(s_bm[1] >> (8 * wave));                                          // 16x8: tile rows 2w, 2w+1
-        P.bitmap[2][i64 * 4 + wave] = (uint8_t)(s_bm[2] >> (8 * wave));                                          // 8x16: tile row w
-        reinterpret_cast<uint16_t*>(P.bitmap[3])[i64 * 4 + wave] = (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1)));   // 8x8: rows 2w, 2w+1
+        if (nib) atomicOr(reinterpret_cast<uint32_t*>(YK2_BM(0)) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave));
+        YK2_BM(1)[i64 * 4 + wave] = (uint8_t)(s_bm[1] >> (8 * wave));                                          // 16x8: tile rows 2w, 2w+1
+        YK2_BM(2)[i64 * 4 + wave] = (uint8_t)(s_bm[2] >> (8 * wave));                                          // 8x16: tile row w
+        reinterpret_cast<uint16_t*>(YK2_BM(3))[i64 * 4 + wave] = (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1)));   // 8x8: rows 2w, 2w+1
         {
             const int sb = wave >> 1;                                        // 8x4: 64x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-            if (BY * 2 + sb < P.yBB32) reinterpret_cast<uint32_t*>(P.bitmap[4])[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)] = s_bm[5 + sb * 2 + (wave & 1)];
+            if (BY * 2 + sb < P.yBB32) reinterpret_cast<uint32_t*>(YK2_BM(4))[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)] = s_bm[5 + sb * 2 + (wave & 1)];
         }
         for (int sx = 0; sx < 2; sx++) {
             if (BX * 2 + sx < P.xBB32) {
                 // 4x8: 32x64 swizzle blocks, tile rows 2w, 2w+1 = one u16;  4x4: 32x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-                reinterpret_cast<uint16_t*>(P.bitmap[5])[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave] = (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1)));
+                reinterpret_cast<uint16_t*>(YK2_BM(5))[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave] = (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1)));
                 const int sy = wave >> 1;
-                if (BY * 2 + sy < P.yBB32) reinterpret_cast<uint32_t*>(P.bitmap[6])[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)] = s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)];
+                if (BY * 2 + sy < P.yBB32) reinterpret_cast<uint32_t*>(YK2_BM(6))[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)] = s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)];
             }
         }
     }
     // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
-    if (P.bounds) {
-        const int b0 = P.bounds[0], b1 = P.bounds[1], b2 = P.bounds[2], b3 = P.bounds[3];
-        discard = P.bounds[4];
+    if (boundsP) {
+        const int b0 = boundsP[0], b1 = boundsP[1], b2 = boundsP[2], b3 = boundsP[3];
+        discard = boundsP[4];
         cxB = (b0 >> 3) << 3; cyB = (b1 >> 3) << 3;
         cw = (((b2 + 7) >> 3) << 3) - cxB; chh = (((b3 + 7) >> 3) << 3) - cyB;
     }
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const bool tileIn = (tgx + 8 <= w) && (tgyl + 8 <= h);
     // LeftRightOrder over the constraint box incl. its zero-size rule (encoder/framework.h:239-255)
     const bool part = tileIn && tgx >= cxB && tgx < cxB + cw && tgy >= cyB && tgy < cyB + chh && (tgx + 8 <= cw) && (tgy + 8 <= chh);
-    const bool keepMT = (P.keep == nullptr) || discard || (mtIn && P.keep[mtIdx] != 0);
+    const bool keepMT = (keepP == nullptr) || discard || (mtIn && keepP[mtIdx] != 0);
     const bool tileLive = part && keepMT;
     const int l00 = lane - cyl * 4 - cxl;                                    // lane of the tile's top-left cell
     const bool v00 = !((cov >> l00) & 1ULL), v10 = !((cov >> (l00 + 1)) & 1ULL), v01 = !((cov >> (l00 + 4)) & 1ULL), v11 = !((cov >> (l00 + 5)) & 1ULL);
@@ -349,13 +361,13 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     if (bd != 0ULL && lane == 0) {
                         const int row = ((BY * 64 + wave * 16) >> 3) + r;
                         const size_t blk = ((size_t)row * P.tilesW + (size_t)BX * 8) >> 10;
-                        atomicAdd(&P.blockCnt[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
-                        atomicAdd(&P.blockCnt[blk * 2 + 1], (uint32_t)__popcll(bd));
+                        atomicAdd(&blockCntP[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
+                        atomicAdd(&blockCntP[blk * 2 + 1], (uint32_t)__popcll(bd));
                     }
                 }
             } else if (writer && n16 > 0) {
-                atomicAdd(&P.blockCnt[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16);
-                atomicAdd(&P.blockCnt[((size_t)tileIdx >> 10) * 2 + 1], 1u);
+                atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16);
+                atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2 + 1], 1u);
             }
         }
     }
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     if (__ballot(valid) == 0ULL || (P.ablate & 1)) {
         if (writer) {
 #pragma unroll
-            for (int p = 0; p < 3; p++) P.tileCount[p * T8 + tileIdx] = 0;
+            for (int p = 0; p < 3; p++) tileCountP[p * T8 + tileIdx] = 0;
         }
     } else {
         uint32_t* lut = &s_lut[tw][0];
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
             // codes of the best mode, nibble-packed at the position of the lane's pixels among the tile's valid pixels (:1174-1190)
             if (valid) {
-                uint8_t* slot = P.slots + ((size_t)p * T8 + tileIdx) * YK_SLOT;
+                uint8_t* slot = slotsP + ((size_t)p * T8 + tileIdx) * YK_SLOT;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int yIn = cyl * 4 + r;
@@ -636,9 +648,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 }
             }
             if (writer) {
-                P.tileCount[p * T8 + tileIdx] = (uint8_t)valueCount;
+                tileCountP[p * T8 + tileIdx] = (uint8_t)valueCount;
                 // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
-                P.tileDef[p * T8 + tileIdx] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (((uint32_t)dist & 255u) << 7) | ((uint32_t)base & 255u));
+                tileDefP[p * T8 + tileIdx] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (((uint32_t)dist & 255u) << 7) | ((uint32_t)base & 255u));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -647,8 +659,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 }
 
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
-    const int nB = P.xBB64 * P.yBB64, group = 8 * YK2_RUN;
-    YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, ((size_t)nB * 2 + 3) & ~(size_t)3, c->stream));    // 16x16 map: strips OR their 4 bits in
+    const int nB = P.xBB64 * P.yBB64 * P.nFrames, group = 8 * YK2_RUN;
+    // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
+    YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
     dim3 grid(((nB + group - 1) / group) * group * 4);
     hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(64), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());

@@ -113,6 +113,27 @@ class HipTileEncoder:
         _chk(self._h, L.yk_set_dst_fill(self._h, dst_fill))
         _chk(self._h, L.yk_encode_tiles(self._h, reject_factor, int(mode3bit_only), int(want_dst)))
 
+    def set_batch(self, frames):
+        """frames: torch int32 cuda tensor [F, n, h, w] (contiguous): F equally shaped images bound in place (yk_set_batch)."""
+        import torch
+        L = lib()
+        assert frames.dtype == torch.int32 and frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        F, n, h, w = frames.shape
+        self.n, self.h, self.w, self.full_h, self.y0 = n, h, w, h, 0
+        _chk(self._h, L.yk_set_image(self._h, w, h, n, 0, h, 0))
+        _chk(self._h, L.yk_set_batch(self._h, F))
+        torch.cuda.current_stream(frames.device).synchronize()          # hand-over fence, see set_image
+        base = frames.data_ptr()
+        ptrs = (C.c_void_p * 4)(*[base + i * h * w * 4 if i < n else None for i in range(4)])
+        _chk(self._h, L.yk_bind_device_batch(self._h, ptrs, w, n * h * w))
+        self._keepalive = frames
+
+    def encode_batch(self, reject_factor: int = 3, mode3bit_only: bool = False):
+        _chk(self._h, lib().yk_encode_batch(self._h, reject_factor, int(mode3bit_only)))
+
+    def select_frame(self, f: int):
+        _chk(self._h, lib().yk_select_frame(self._h, f))
+
     def encode_frame(self, reject_factor: int = 3, mode3bit_only: bool = False):
         """alpha reject + fused kernel + compaction as one replayed hipGraph launch (whole images; see yk_encode_frame)."""
         _chk(self._h, lib().yk_encode_frame(self._h, reject_factor, int(mode3bit_only)))
