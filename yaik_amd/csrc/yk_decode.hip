@@ -81,36 +81,57 @@ __global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __r
 }
 
 // phase 4: integer bilinear fill with truncation (:160-188, :762-781, :1382-1401) + tile4x4Mask marking.
-// One workgroup per bitmap word, its 256 threads share the tiles of the word.
+// One workgroup per bitmap word.  The word's tiles are listed in LDS and the (tile, channel, row, run) items are spread over all 256
+// threads, so small tiles keep the workgroup as busy as large ones.  A thread produces a run of min(TX, 8) pixels of one row
+// and channel: in the 8x8-tiled plane layout that run is contiguous and leaves as ONE 8-byte (or 4-byte) store.
 __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
                                                             const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
                                                             uint32_t* __restrict__ tile4, int stride4) {
+    __shared__ int s_xy[32][2];
     const size_t wi = blockIdx.x;
-    uint32_t bits = bitmap[wi];
+    const uint32_t bits = bitmap[wi];
     if (!bits) return;
-    const int TX = 1 << g.sx, TY = 1 << g.sy, dx = TX >> 2, dy = TY >> 2, npx = TX * TY;
-    while (bits) {
-        const int b = __ffs(bits) - 1; bits &= bits - 1;
-        const uint32_t pos = (uint32_t)(wi * 32 + b);
-        int x, y; yk_dtile_from_bit(g, pos, x, y);
-        if (x + TX > w || y + TY > h) continue;
+    const int TX = 1 << g.sx, TY = 1 << g.sy, dx = TX >> 2, dy = TY >> 2;
+    const int lgGpr = g.sx > 3 ? g.sx - 3 : 0, lgPer = g.sy + lgGpr;            // runs per row, runs per channel (powers of two)
+    const int GW = TX < 8 ? TX : 8, gpr = 1 << lgGpr, perCh = 1 << lgPer, nEl = 3 * perCh, sh = g.sx + g.sy;
+    if (threadIdx.x < 32 && ((bits >> threadIdx.x) & 1u)) {
+        int x, y; yk_dtile_from_bit(g, (uint32_t)(wi * 32 + threadIdx.x), x, y);
+        const int k = __popc(bits & ((1u << threadIdx.x) - 1u));
+        s_xy[k][0] = (x + TX > w || y + TY > h) ? -1 : x; s_xy[k][1] = y;
+    }
+    __syncthreads();
+    const int nT = __popc(bits);
+    for (int item = threadIdx.x; item < nT * nEl; item += 256) {
+        const int ck = item >> lgPer, k = ck / 3, c = ck - 3 * k;               // tile of the word, channel
+        const int x = s_xy[k][0], y = s_xy[k][1];
+        if (x < 0) continue;
+        const int r = item & (perCh - 1), ty = r >> lgGpr, gx = (r & (gpr - 1)) * GW;
         const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
-        for (int e = threadIdx.x; e < npx * 3; e += 256) {
-            const int c = e / npx, p = e - c * npx, tx = p & (TX - 1), ty = p >> g.sx;
-            const int TL = mapRGB[l0 * 3 + c], TR = mapRGB[(l0 + dx) * 3 + c];
-            const int BL = mapRGB[(l0 + (size_t)dy * latW) * 3 + c], BR = mapRGB[(l0 + (size_t)dy * latW + dx) * 3 + c];
-            const int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
-            const int xx = x + tx, yy = y + ty;
-            planes[(size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7)] =
-                (uint8_t)((L * (TX - tx) + R * tx) >> (g.sx + g.sy));
-        }
-        // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953)
-        for (int e = threadIdx.x; e < dx * dy; e += 256) {
-            const int cx = (x >> 2) + (e % dx), cy = (y >> 2) + (e / dx);
-            const size_t byteIdx = (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
-            const uint32_t bit = (uint32_t)((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
-            atomicOr(&tile4[byteIdx >> 2], 1u << (bit + 8 * (byteIdx & 3)));
-        }
+        const int TL = mapRGB[l0 * 3 + c], TR = mapRGB[(l0 + dx) * 3 + c];
+        const int BL = mapRGB[(l0 + (size_t)dy * latW) * 3 + c], BR = mapRGB[(l0 + (size_t)dy * latW + dx) * 3 + c];
+        const int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
+        int v = L * (TX - gx) + R * gx;                                         // numerator at the first pixel of the run, + (R - L) per pixel
+        const int xx = x + gx, yy = y + ty;
+        uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - L; }
+        if (GW == 8) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - L; }
+            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+        } else *reinterpret_cast<uint32_t*>(o) = lo;
+    }
+    // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953)
+    const int lgCells = (g.sx - 2) + (g.sy - 2);
+    for (int item = threadIdx.x; item < (nT << lgCells); item += 256) {
+        const int k = item >> lgCells, e = item & ((1 << lgCells) - 1);
+        const int x = s_xy[k][0], y = s_xy[k][1];
+        if (x < 0) continue;
+        const int cx = (x >> 2) + (e & (dx - 1)), cy = (y >> 2) + (e >> (g.sx - 2));
+        const size_t byteIdx = (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
+        const uint32_t bit = (uint32_t)((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+        atomicOr(&tile4[byteIdx >> 2], 1u << (bit + 8 * (byteIdx & 3)));
     }
 }
 
