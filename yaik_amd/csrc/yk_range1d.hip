@@ -159,18 +159,18 @@ __global__ __launch_bounds__(1024) void yk_range1d_pack_kernel(const uint32_t* _
         s_offT[threadIdx.x] = baseTiles[blockIdx.x] + et; s_offP[threadIdx.x] = basePix[blockIdx.x] + ep; s_n[threadIdx.x] = cp;
     }
     __syncthreads();
-    const int l16 = threadIdx.x & 15;
-    for (int it = 0; it < 16; it++) {
-        const int t = it * 64 + (threadIdx.x >> 4);
+    // every tile holds a multiple of 16 bytes and all offsets are multiples of 16: four lanes per tile copy 16-byte pieces
+    const int piece = threadIdx.x & 3;
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 256 + (threadIdx.x >> 2);
         const size_t i = i0 + t;
         if (i >= T8) break;
         const uint32_t n = s_n[t];
         if (!n) continue;
         const size_t po = (size_t)p * totals[1] + s_offP[t];
-        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(slots + ((size_t)p * T8 + i) * 64);
-        uint32_t* o4 = reinterpret_cast<uint32_t*>(pixOut + po);
-        if ((uint32_t)l16 * 4 < n) o4[l16] = s4[l16];
-        if (l16 == 0) {
+        if ((uint32_t)piece * 16 < n)
+            *reinterpret_cast<uint4*>(pixOut + po + piece * 16) = *reinterpret_cast<const uint4*>(slots + ((size_t)p * T8 + i) * 64 + piece * 16);
+        if (piece == 0) {
             const size_t to = ((size_t)p * totals[0] + s_offT[t]) * 3;
             const uint8_t* qp = params + ((size_t)p * T8 + i) * 4;
             typeOut[to] = qp[0]; typeOut[to + 1] = qp[1]; typeOut[to + 2] = qp[2];
