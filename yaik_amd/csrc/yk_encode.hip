@@ -540,15 +540,13 @@ __global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restric
     if (threadIdx.x == 0) { blockCnt[(size_t)blockIdx.x * 2] = totN; blockCnt[(size_t)blockIdx.x * 2 + 1] = tot2; }
 }
 
-// second level: exclusive prefix over the per-block sums (consumed and cleared for the next frame), totals for the three
-// planes, and the words of the nibble streams that two blocks share: yk_pack_kernel ORs into those, so they are cleared here;
-// every other word of a stream is written whole.
+// second level: exclusive prefix over the per-block sums (consumed and cleared for the next frame) and the totals of the
+// three planes (identical: the counts do not depend on the plane).
 __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
-                                                        uint32_t* __restrict__ totals, uint32_t* __restrict__ nib, size_t strideWords,
-                                                        unsigned long long blockNStride, unsigned long long nibFrameWords) {
+                                                        uint32_t* __restrict__ totals, unsigned long long blockNStride) {
     __shared__ uint32_t s_tmp[32];
     blockCnt += (size_t)blockIdx.x * blockNStride; blockSums += (size_t)blockIdx.x * blockNStride;     // blockIdx.x = frame of a batch
-    totals += (size_t)blockIdx.x * 8; nib += (size_t)blockIdx.x * nibFrameWords;
+    totals += (size_t)blockIdx.x * 8;
     uint32_t baseN = 0, baseD = 0;
     for (int start = 0; start < nBlocks; start += 1024) {
         const int i = start + threadIdx.x;
@@ -559,77 +557,48 @@ __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ b
         if (i < nBlocks) {
             blockSums[i * 2] = baseN + en; blockSums[i * 2 + 1] = baseD + ed;
             blockCnt[i * 2] = 0; blockCnt[i * 2 + 1] = 0;
-            const uint32_t w = (baseN + en) >> 3;
-#pragma unroll
-            for (int p = 0; p < 3; p++) { uint32_t* o = nib + (size_t)p * strideWords; o[w] = 0; if (w) o[w - 1] = 0; }
         }
         baseN += totN; baseD += totD;
     }
-    if (threadIdx.x < 3) {
-        const int p = threadIdx.x;
-        totals[p * 2] = baseD; totals[p * 2 + 1] = baseN;
-        uint32_t* o = nib + (size_t)p * strideWords;
-        const uint32_t w = baseN >> 3; o[w] = 0; o[w + 1] = 0; if (w) o[w - 1] = 0;
-    }
+    if (threadIdx.x < 3) { totals[threadIdx.x * 2] = baseD; totals[threadIdx.x * 2 + 1] = baseN; }
 }
 
-// One workgroup packs the nibbles of 1024 consecutive tiles: the per-tile slots are read as whole 16-byte vectors, shifted
-// into place in an LDS image of the block's piece of the stream, and that piece goes out as one contiguous run of words.
+// One workgroup packs the nibbles of 1024 consecutive tiles.  Every tile holds a multiple of 16 nibbles (16 per uncovered 4x4
+// quadrant), so every stream offset is a multiple of 8 bytes: after the scan, four lanes per tile copy 8-byte pieces of the
+// tile's slot straight to its place in the stream, reading only the bytes that exist.
 __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
                                                        const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
                                                        uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords, YkFrameStrides fs) {
     __shared__ uint32_t s_tmp[32];
-    __shared__ uint32_t s_out[YK_SCAN_TILE * 8 + 8];
+    __shared__ uint32_t s_off[YK_SCAN_TILE];
+    __shared__ uint8_t s_cnt[YK_SCAN_TILE];
     {   // blockIdx.z = frame of a batch
         const size_t f = blockIdx.z;
         tileCount += f * fs.tileCount; tileDef += f * fs.tileDef; slots += f * fs.slots; blockSums += f * fs.blockN;
         defsOut += f * fs.defsOut; nibOut += f * (fs.nibOut / 4);
     }
     const int p = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
-    const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
-    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (c) {
-        const uint4* sl = reinterpret_cast<const uint4*>(slots + ((size_t)p * T8 + i) * YK_SLOT);
-        const uint4 lo = sl[0];
-        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-        if (c > 32) { const uint4 hi = sl[1]; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w; }
-    }
-    uint32_t totN, totD;
-    const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
-    const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
-    if (totN == 0) return;                                                    // uniform over the workgroup
-    const uint32_t baseN = blockSums[(size_t)blockIdx.x * 2], baseD = blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
-    const uint32_t sh0 = baseN & 7u;
-    const uint32_t nWords = (sh0 + totN + 7) >> 3;
-    for (uint32_t k = threadIdx.x; k < nWords; k += YK_SCAN_TILE) s_out[k] = 0;
-    __syncthreads();
-    if (c) {
-        defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
-        // c nibbles of the slot (low nibble first) go to nibble offset o of the LDS image
-        const uint32_t o = sh0 + en;
-        const uint32_t sh = (o & 7u) * 4u;
-        const uint32_t firstW = o >> 3, lastW = (o + c - 1) >> 3;
-        uint32_t prev = 0;
-#pragma unroll
-        for (uint32_t k = 0; k <= 8; k++) {
-            uint32_t cur = 0;
-            if (k < 8 && k * 8 < c) {
-                cur = w[k];
-                const uint32_t rem = c - k * 8;                   // nibbles of this word that are real
-                if (rem < 8) cur &= (1u << (rem * 4)) - 1u;
-            }
-            const uint32_t outw = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32u - sh));
-            prev = cur;
-            const uint32_t wi = firstW + k;
-            if (wi <= lastW) { if (wi == firstW || wi == lastW) atomicOr(&s_out[wi], outw); else s_out[wi] = outw; }
-        }
+    const size_t i0 = (size_t)blockIdx.x * YK_SCAN_TILE;
+    {
+        const size_t i = i0 + threadIdx.x;
+        const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+        uint32_t totN, totD;
+        const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
+        const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
+        const uint32_t baseN = blockSums[(size_t)blockIdx.x * 2], baseD = blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
+        s_off[threadIdx.x] = (baseN + en) >> 1;                                   // byte offset inside the plane's stream
+        s_cnt[threadIdx.x] = (uint8_t)c;
+        if (c) defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
     }
     __syncthreads();
-    uint32_t* out = nibOut + (size_t)p * nibStrideWords + (baseN >> 3);
-    for (uint32_t k = threadIdx.x; k < nWords; k += YK_SCAN_TILE) {
-        const uint32_t v = s_out[k];
-        if (k == 0 || k == nWords - 1) { if (v) atomicOr(&out[k], v); } else out[k] = v;
+    uint8_t* out = reinterpret_cast<uint8_t*>(nibOut + (size_t)p * nibStrideWords);
+    const int piece = threadIdx.x & 3;
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 256 + (threadIdx.x >> 2);
+        const size_t i = i0 + t;
+        if (i >= T8) break;
+        if (piece * 8 < (s_cnt[t] >> 1))
+            *reinterpret_cast<uint2*>(out + s_off[t] + piece * 8) = *reinterpret_cast<const uint2*>(slots + ((size_t)p * T8 + i) * YK_SLOT + piece * 8);
     }
 }
 
@@ -693,8 +662,7 @@ int yk_launch_pack(yk_ctx* c, bool batch) {
     uint32_t* blockCnt = batch ? c->B.blockCnt : c->blockCnt; uint32_t* blockSums = batch ? c->B.blockSums : c->blockSums;
     uint32_t* totals = batch ? c->B.totals : c->totals; uint8_t* nibOut = batch ? c->B.nibOut : c->nibOut;
     if (c->kernelVersion != 2) hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockCnt);
-    hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals,
-                       reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, (unsigned long long)c->fs.blockN, (unsigned long long)(c->fs.nibOut / 4));
+    hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals, (unsigned long long)c->fs.blockN);
     hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3, F), dim3(1024), 0, c->stream, batch ? c->B.tileCount : c->tileCount, batch ? c->B.tileDef : c->tileDef,
                        batch ? c->B.slots : c->slots, T8, blockSums, nb, batch ? c->B.defsOut : c->defsOut, reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, c->fs);
     YK_HIP(c, hipGetLastError());
