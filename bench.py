@@ -4,7 +4,8 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--mode3] [--in-flight F] [--no-cpu] [--no-parity]
 
-One "step" = one pass of the hot path over one frame per GPU (F frames with --in-flight F):
+One "step" = one pass of the hot path over a batch of F frames per GPU kept in flight on F handles/streams (--in-flight F, default 2:
+the HBM-bound alpha / pack kernels of one frame run under the VALU-bound fused kernel of the other; --in-flight 1 = one frame at a time):
     yk_alpha_reject -> yk_alpha_finish -> yk_encode_tiles (fused gradient+range kernel, then stream compaction)
     and, for N > 1, ONE RCCL gather of the per-rank tile maps onto rank 0 (frame sharding, weak scaling), double-buffered so
     that the transfer of frame i rides under the kernels of frame i+1, and verified by checksums outside the timed region.
@@ -34,8 +35,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--mode3", action="store_true", help="3-bpp range modes only (DynamicTileEncode mode3BitOnly)")
-    ap.add_argument("--in-flight", type=int, default=1, help="frames per GPU encoded concurrently on separate handles/streams (a step = that many "
-                    "frames per GPU; 2 hides the HBM-bound alpha/pack kernels behind the VALU-bound fused kernel of the other frame)")
+    ap.add_argument("--in-flight", type=int, default=2, help="frames per GPU kept in flight on separate handles/streams (a step = that many frames per "
+                    "GPU).  Default 2: a stream of frames, where the HBM-bound alpha / pack kernels of one frame run under the VALU-bound fused "
+                    "kernel of the other (the fused kernels themselves do not overlap: each fills the chip); 1 = strictly one frame at a time")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU held by ONE handle and encoded with one launch per kernel (yk_encode_batch): "
                     "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
@@ -81,7 +83,8 @@ def main() -> int:
     K = max(1, args.in_flight)
     BF = max(0, args.batch)
     if BF:
-        if world > 1 or K > 1 or args.graph:
+        K = 1
+        if world > 1 or args.graph:
             print("--batch is a single-GPU, single-handle mode", file=sys.stderr)
             return 2
         batch = torch.stack([synth_planes_torch(W, n_planes=4, seed=12345 + j, device=dev) for j in range(BF)]).contiguous()
@@ -215,7 +218,7 @@ def main() -> int:
     # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh); only valid for the default workload
     traffic, traffic_src = None, None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-    if os.path.exists(tpath) and W == 8192 and not args.mode3 and K == 1 and not BF:
+    if os.path.exists(tpath) and W == 8192 and not args.mode3 and K <= 2 and not BF:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("kernel") == "yk_encode2_kernel":
@@ -231,7 +234,10 @@ def main() -> int:
         roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
     elif args.graph:
         roofline["note"] = "--graph: kernel_ms is the whole frame (alpha stage + fused kernel + compaction replayed as one hipGraph)"
-    elif K > 1:
+    elif K == 2:
+        roofline["note"] = ("2 frames in flight: the fused kernels of the two frames run one after the other (each fills the chip); the alpha / pack "
+                            "intervals in other_kernels_ms include the time those stages queue behind the other frame's fused kernel")
+    elif K > 2:
         roofline["note"] = f"{K} frames in flight: each kernel's duration includes the time it shares the chip with the other frame's kernels"
 
     result = {
