@@ -49,10 +49,27 @@ __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (
 
 // One gradient pass for the four macro-tiles of a wave.  Arithmetic identical to yk_grad_pass (see yk_encode.hip): with
 // 1/16-unit weights S' = (TL*lx+TR*rx)*wy + (BL*lx+BR*rx)*wb fits 16 bits and the six variants of EncoderContext.cpp:3929-3991
-// are range tests on D = S' - 256*cur per corner set.
+// are range tests on D = S' - 256*cur per corner set.  Here the arithmetic is PACKED: two 16-bit streams per VALU op.
+//   * streams: t = 0..2: channel t of (raw corners | Round6 corners); t = 3: Round6P corners of (channel 0 | channel 1);
+//     t = 4: Round6P corners of channel 2 (both halves).  The corner values come from a per-strip lattice table in LDS that is
+//     already in this layout (s_lat[t][17x5 lattice points], built once per strip).
+//   * S' is bilinear inside a tile, so a stream is (S, step) at one pixel plus three constants, all in the ring Z/2^16 (the true
+//     S' lies in [0, 65280], so the ring value is exact): rows are walked in serpentine order with one packed subtract per pixel.
+//   * D = S' - 256*cur is formed with signed saturation on operands biased by -32768 (pixel bytes ^ 0x80, S' ^ 0x8000); the
+//     bounds of the tests are at most 256*rf + 255 <= 30975 for rf <= 120 (the launcher routes larger rejectFactors to
+//     yk_encode_kernel), so a saturated D compares like the true D.  Only min D / max D per stream are tracked.
+typedef short y2s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short y2u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ y2u2 y2_u2(uint32_t w) { return __builtin_bit_cast(y2u2, w); }
+__device__ __forceinline__ y2s2 y2_s2(y2u2 v) { return __builtin_bit_cast(y2s2, v); }
+__device__ __forceinline__ y2u2 y2_splat(int v) { const unsigned short t = (unsigned short)v; return (y2u2){ t, t }; }
+__device__ __forceinline__ y2s2 y2_splats(int v) { const short t = (short)v; return (y2s2){ t, t }; }
+#define YK2_LATN 85                                                      // 17 x 5 lattice points (every 4th pixel incl. the halo) per strip
+#define YK2_RFMAX 120
+
 template <int SX, int SY>
-__device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lcell, const int cx, const int cy, const int lane,
-                                             const uint32_t (&pw)[16], unsigned long long& cov, const unsigned long long deadLanes,
+__device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy, const int lane,
+                                             const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes,
                                              const int gxCell, const int gyCell, const int w, const int h, const int rf,
                                              uint32_t* s_bm, const int bxCell, const int byCell) {
     constexpr int TX = 1 << SX, TY = 1 << SY, NX = TX / 4, NY = TY / 4;
@@ -67,65 +84,77 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_pix, const int lc
     bool viable = allow && ((deadLanes & tm) == 0ULL);
     if (__ballot(viable) == 0ULL) return;
 
-    const int lo = lcell - (dcy * 4) * LS - dcx * 4;                     // LDS word of the tile origin
-    const uint32_t cw[4] = { s_pix[lo], s_pix[lo + TX], s_pix[lo + TY * LS], s_pix[lo + TY * LS + TX] };   // TL, TR, BL, BR
-    int cr[3][3][4];                                                     // [set][channel][corner]
+    // per stream: S (at the current pixel, biased), step along x, and the constants of the walk
+    const int lo = lat - dcy * 17 - dcx;                                 // lattice index of the tile origin
+    const y2u2 wy2 = y2_splat(16 - ((dcy * 4) << (4 - SY)));             // weight of the cell's first pixel row
+    const y2u2 lx2 = y2_splat(16 - ((dcx * 4) << (4 - SX)));             // weight of the cell's first pixel column
+    y2u2 S[5], st[5], dS0[5], dS3[5], dst[5];
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++)
+    for (int t = 0; t < 5; t++) {
+        const uint32_t* lt = s_lat + t * YK2_LATN + lo;
+        const y2u2 TL = y2_u2(lt[0]), TR = y2_u2(lt[NX]), BL = y2_u2(lt[NY * 17]), BR = y2_u2(lt[NY * 17 + NX]);
+        // L(r) = 16 BL + (TL-BL) wy, R(r) = 16 BR + (TR-BR) wy, dL = L - R, S'(x0) = 16 R + dL lx0, step = dL * 16/TX, wy(r) = wy0 - r * 16/TY
+        const y2u2 e16 = (BL - BR) << 4, g = TR - BR, f = TL - BL - g;
+        const y2u2 c2 = (g << 4) + f * lx2;
+        S[t] = ((BR << 8) + e16 * lx2 + c2 * wy2) ^ y2_splat(0x8000);
+        dS0[t] = c2 << (4 - SY);                                         // S'(x0, r) - S'(x0, r+1)
+        st[t] = (e16 + f * wy2) << (4 - SX);                             // S'(x, r) - S'(x+1, r)
+        dst[t] = f << (8 - SX - SY);                                     // step(r) - step(r+1)
+        dS3[t] = dS0[t] - dst[t] * (unsigned short)3;                    // S'(x0+3, r) - S'(x0+3, r+1)
+    }
+    const int loO = -256 * rf, hiO = 256 * rf + 255;
+    const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
+    y2s2 mn[5], mx[5];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int v = y2_byte(cw[k], ch);
-            cr[0][ch][k] = v; cr[1][ch][k] = y2_round6(v); cr[2][ch][k] = y2_round6p(v);
-        }
-    const int lx0 = 16 - ((dcx * 4) << (4 - SX));                        // weight of the cell's first pixel column
-    const int loO = -256 * rf, hiO = 256 * rf + 255, loR = loO - 127, hiR = hiO - 127;
-    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    for (int t = 0; t < 5; t++) { mn[t] = y2_splats(32767); mx[t] = y2_splats(-32768); }
+    unsigned long long bO[3], bR[3];
+    auto variants = [&]() {                                              // lanes failing each of the six variants, so far
+        const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]);   // (raw | Round6) over the channels
+        const y2s2 mxA = __builtin_elementwise_max(__builtin_elementwise_max(mx[0], mx[1]), mx[2]);
+        const y2s2 mnP = __builtin_elementwise_min(mn[3], mn[4]), mxP = __builtin_elementwise_max(mx[3], mx[4]);   // Round6P, either half
+        const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
+        const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
+        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
+        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
+        bO[0] = __ballot(oA.x > 0); bO[1] = __ballot(oA.y > 0); bO[2] = __ballot((oP.x > 0) | (oP.y > 0));
+        bR[0] = __ballot(rA.x > 0); bR[1] = __ballot(rA.y > 0); bR[2] = __ballot((rP.x > 0) | (rP.y > 0));
+    };
 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int wy = 16 - ((dcy * 4 + r) << (4 - SY)), wb = 16 - wy;
-        int cc[12];                                                      // 256 * current pixel, this row only (bounds live registers)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            cc[i * 3 + 0] = (int)((pw[r * 4 + i] << 8) & 0xFF00u);
-            cc[i * 3 + 1] = (int)(pw[r * 4 + i] & 0xFF00u);
-            cc[i * 3 + 2] = (int)((pw[r * 4 + i] >> 8) & 0xFF00u);
-        }
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = (r & 1) ? 3 - ii : ii;                         // serpentine: odd rows right to left
+            const uint32_t p = pwb[r * 4 + i];
+            // 256 * (cur - 128) of channel c in both halves; stream 3: channel 0 | channel 1
+            const y2s2 cc[4] = { y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x000C000Cu))), y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C010Cu))),
+                                 y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu))), y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))) };
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int L = cr[s][ch][0] * wy + cr[s][ch][2] * wb, R = cr[s][ch][1] * wy + cr[s][ch][3] * wb;
-                const int dL = L - R;
-                int S = (R << 4) + dL * lx0;                             // S' of the first pixel of the row
-                const int step = dL << (4 - SX);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int D = S - cc[i * 3 + ch];
-                    mn[s] = min(mn[s], D); mx[s] = max(mx[s], D);
-                    S -= step;
-                }
+            for (int t = 0; t < 5; t++) {
+                const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(S[t]), cc[t == 4 ? 2 : t]);
+                mn[t] = __builtin_elementwise_min(mn[t], D); mx[t] = __builtin_elementwise_max(mx[t], D);
+                if (ii < 3) S[t] = (r & 1) ? S[t] + st[t] : S[t] - st[t];
             }
+        }
+        if (r < 3) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) { S[t] -= (r & 1) ? dS0[t] : dS3[t]; st[t] -= dst[t]; }
         }
         if (r == 0) {
             // after one row: a tile is already lost if each of its six variants has a failing lane; if that holds for every
             // viable tile of the wave the remaining three rows cannot change any decision.
+            variants();
             bool lost = true;
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const unsigned long long bO = __ballot((mn[s] < loO) | (mx[s] > hiO)), bR = __ballot((mn[s] < loR) | (mx[s] > hiR));
-                lost = lost && ((bO & tm) != 0ULL) && ((bR & tm) != 0ULL);
-            }
+            for (int s = 0; s < 3; s++) lost = lost && ((bO[s] & tm) != 0ULL) && ((bR[s] & tm) != 0ULL);
             viable = viable && !lost;
             if (__ballot(viable) == 0ULL) return;
         }
     }
+    variants();
     bool anyPass = false;                                                // :3998
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const unsigned long long bO = __ballot((mn[s] < loO) | (mx[s] > hiO)), bR = __ballot((mn[s] < loR) | (mx[s] > hiR));
-        anyPass = anyPass || ((bO & tm) == 0ULL) || ((bR & tm) == 0ULL);
-    }
+    for (int s = 0; s < 3; s++) anyPass = anyPass || ((bO[s] & tm) == 0ULL) || ((bR[s] & tm) == 0ULL);
     const bool accept = viable && anyPass;
     cov |= __ballot(accept);                                             // paint coverage (:4029-4037): bit = lane = cell
     if (accept && dcx == 0 && dcy == 0) {                                // the origin cell's lane sets the bitmap bit (:4026)
@@ -157,9 +186,13 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
-    __shared__ __attribute__((aligned(16))) float s_chain[6][68];           // exact-order fallback, one tile-plane at a time
-    __shared__ float s_err[8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_small[256];          // small-range tiles: 16 bins / 16 table entries per tile
+    // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
+    // time), its mode sums, and the small-range tiles' 16 bins / 16 table entries per tile
+    __shared__ __attribute__((aligned(16))) uint32_t s_aux[672];
+    uint32_t* const s_lat = s_aux;
+    float (*const s_chain)[68] = reinterpret_cast<float (*)[68]>(s_aux);
+    float* const s_err = reinterpret_cast<float*>(s_aux + 408);
+    uint32_t* const s_small = s_aux + 416;
 
     const int lane = threadIdx.x;
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
@@ -252,11 +285,29 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
 
+    // ---- corner lattice (every 4th pixel, 17 x 5 points incl. the halo): Round6 / Round6P of the three channels at once (SWAR)
+    // and the five packed streams of y2_grad_pass
+    for (int idx = lane; idx < YK2_LATN; idx += 64) {
+        const int lr = idx / 17, lc = idx - lr * 17;
+        const uint32_t raw = s_pix[(lr * 4) * LS + lc * 4];
+        const uint32_t r6 = (raw & 0x00FCFCFCu) | ((raw >> 6) & 0x00030303u);                    // EncoderContext.cpp:3183
+        const uint32_t z = (raw & 0x007F7F7Fu) + 0x00010101u;
+        const uint32_t inc = (z ^ (raw & 0x00808080u)) | (((z & raw & 0x00808080u) >> 7) * 255u);   // min(v + 1, 255) per byte
+        const uint32_t p6 = (inc & 0x00FCFCFCu) | ((inc >> 6) & 0x00030303u);                    // EncoderContext.cpp:3202
+        s_lat[0 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C040C00u);
+        s_lat[1 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C050C01u);
+        s_lat[2 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C060C02u);
+        s_lat[3 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C010C00u);
+        s_lat[4 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C020C02u);
+    }
+    __syncthreads();
+
     // ---- lane geometry: wave = macro-tile row `wave` of the block, lane = macroTile(q)*16 + cellY*4 + cellX ------------
     const int q = lane >> 4, cell = lane & 15, cx = cell & 3, cy = cell >> 2;
     const int bxCell = q * 16 + cx * 4, byCell = wave * 16 + cy * 4;          // cell origin inside the block
     const int gxCell = BX * 64 + bxCell, gyCell = BY * 64 + byCell;          // stripe-local pixels
     const int lcell = (cy * 4) * LS + bxCell;                                // strip-local LDS word of the cell origin
+    const int lat = cy * 17 + q * 4 + cx;                                    // lattice index of the cell origin
     const bool mtIn = (BX * 64 + q * 16 < w) && (BY * 64 + wave * 16 < h);    // macro-tile origin inside the image
 
     uint32_t pw[16];
@@ -284,15 +335,19 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         const unsigned long long deadLanes = __ballot(dead);
         if (~deadLanes != 0ULL && !(P.ablate & 2)) {
-            y2_grad_pass<4, 4>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+#pragma unroll
+            for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
+            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
             if (~(cov | deadLanes) != 0ULL) {
-                y2_grad_pass<4, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 4>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 2>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 3>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 2>(s_pix, lcell, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
             }
+#pragma unroll
+            for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
         }
     }
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
