@@ -72,10 +72,11 @@ def test_per_pixel_search_path_bit_exact(oracle_built, case):
         e.close()
 
 
-@pytest.mark.parametrize("rf", [0, 1, 2, 5, 9])
+@pytest.mark.parametrize("rf", [0, 1, 2, 5, 9, 40, 64])
 def test_other_reject_factors_bit_exact(hip, oracle_built, rf):
     """FittingQuadSmooth's rejectFactor is an argument of the operator (the shipped encoder always passes 3): the range tests on
-    D = S' - 256*cur and the second-difference early-out are parametrised by it."""
+    D = S' - 256*cur and the second-difference early-out are parametrised by it.  64 is the largest factor the C-ABI admits (the packed
+    16-bit tests of yk_encode2_kernel need 256*rf + 255 inside int16)."""
     from oracle.pyoracle import PASSES, OracleEncoder
     from tests.parity import cells_from_plane
     for planes in (synth_planes(256, n_planes=3), edge_image(128, 128, "smooth", 3), edge_image(128, 128, "mixed", 3)):

@@ -38,6 +38,16 @@ def test_reciprocal_model1_division_is_exact(hip):
     assert res.value == 0, f"{res.value} (n, delta) pairs differ from the integer division of GetValueModel1"
 
 
+def test_quantiser_table_matches_lut_scan(hip):
+    """yk_encode2_kernel reads index / minDiff of a pixel from a table indexed by (rangeDecode, v - BN): for every (min, max) of a
+    tile the LUTs built the reference's way must equal BN + K[rangeDecode], and every value in [min, max] must find in the table
+    what the first-minimum scan of those LUTs finds."""
+    from yaik_amd._lib import lib
+    res = C.c_int(-1)
+    assert lib().yk_selftest(hip._h, 3, C.byref(res)) == 0
+    assert res.value == 0, f"{res.value} table entries differ from the LUT scan"
+
+
 CORNER_CASES = {
     "synth256x4": lambda: synth_planes(256, n_planes=4), "synth512x3": lambda: synth_planes(512, n_planes=3),
     "mixed128": lambda: edge_image(128, 128, "mixed"), "ramp200x136": lambda: edge_image(200, 136, "ramp"),

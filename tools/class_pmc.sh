@@ -1,12 +1,14 @@
 # per-class instruction budget of the fused kernel (run on the GPU box): classes x ablation flags
+#   usage: tools/class_pmc.sh "frame ramp mild noise" "0 1"
 set -e
-for c in frame; do for a in 0 1 3; do
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d gpurun_out/cls/${c}_$a -- python3 tools/gpu_class_pmc.py $c $a > gpurun_out/cls_${c}_$a.log 2>&1
+CLS=${1:-"frame ramp mild noise"}; ABL=${2:-"0 1"}
+for c in $CLS; do for a in $ABL; do
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/cls/${c}_$a -- python3 tools/gpu_class_pmc.py $c $a > gpurun_out/cls_${c}_$a.log 2>&1
 done; done
-python3 - <<'PY'
-import csv, glob, collections
-for c in ("frame",):
-  for a in (0,1,3):
+CLS="$CLS" ABL="$ABL" python3 - <<'PY'
+import csv, glob, collections, os
+for c in os.environ["CLS"].split():
+  for a in os.environ["ABL"].split():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(f"gpurun_out/cls/{c}_{a}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):

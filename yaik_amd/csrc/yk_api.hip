@@ -101,6 +101,7 @@ int yk_create(int device, yk_ctx** out) {
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return YK_ERR_HIP; }
     c->stream = c->ownStream;
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (hipEventCreate(&c->evRing[r][i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
+    if (yk_qtab_get(c) != YK_OK) { yk_destroy(c); return YK_ERR_HIP; }
     *out = c;
     return YK_OK;
 }

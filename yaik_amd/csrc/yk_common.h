@@ -41,12 +41,14 @@ struct YkEncodeParams {
     int tilesW, tilesH, mtW, mtH;
     int xBB64, yBB64, xBB32, yBB32;
     int nFrames;            // 1 unless launched by yk_encode_batch
+    const uint8_t* qtab;    // quantiser table of yk_encode2_kernel (yk_qtab_get)
     YkFrameStrides fs;
 };
 
 struct yk_ctx {
     int device = -1;
     int numCU = 256;             // compute units of the device (persistent grids are sized from it)
+    const uint8_t* qtab = nullptr;   // per-device quantiser table (owned by the library, shared by all handles)
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -127,3 +129,5 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
 int yk_launch_pack(yk_ctx* c, bool batch = false);
 int yk_launch_corners(yk_ctx* c);
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P);
+int yk_qtab_get(yk_ctx* c);                              // builds the device's quantiser table on first use, sets c->qtab
+void yk_selftest_qtab_launch(yk_ctx* c, int* mismatches);

@@ -648,6 +648,7 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
     P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
     P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
     P.nFrames = batch ? c->nFrames : 1; P.fs = c->fs;
+    P.qtab = c->qtab;
     if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
     if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
     dim3 grid(P.xBB64, P.yBB64);
@@ -708,6 +709,7 @@ extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     if (which == 0) hipLaunchKernelGGL(yk_selftest_div_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else if (which == 1) hipLaunchKernelGGL(yk_selftest_scale_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else if (which == 2) hipLaunchKernelGGL(yk_selftest_r1div_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 3) yk_selftest_qtab_launch(c, d);
     else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
     YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));

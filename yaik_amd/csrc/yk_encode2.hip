@@ -20,6 +20,7 @@
 #include "yk_common.h"
 #include "yk_curves.h"
 #include "yk_device.h"
+#include <mutex>
 
 __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 
@@ -28,22 +29,6 @@ __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
 // |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
 __device__ __forceinline__ uint32_t y2_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// key = (minDiff << 8) | index of the FIRST nearest LUT entry (the reference's `<` scan, EncoderContext.cpp:873-881):
-// v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n, so a plain min does it.  4-bit modes: the LUT is sorted, two compares against the
-// stored midpoints pick the quarter (ties go down), one per-lane 16-byte LDS read fetches its four entries.
-__device__ __forceinline__ uint32_t y2_search16(const uint32_t* lm, uint32_t H1, uint32_t H2, uint32_t H3, uint32_t x) {
-    const bool c2 = x > H2;
-    const bool c1 = x > (c2 ? H3 : H1);
-    const uint32_t qd = (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
-    const uint4 E = *reinterpret_cast<const uint4*>(lm + qd * 4);
-    return min(min(y2_absdiff(E.x, x), __usad(E.y, x, 1u)), min(__usad(E.z, x, 2u), __usad(E.w, x, 3u))) + qd * 4u;
-}
-__device__ __forceinline__ uint32_t y2_search8(const uint32_t (&e)[8], uint32_t x) {
-    uint32_t key = y2_absdiff(e[0], x);
-#pragma unroll
-    for (int n = 1; n < 8; n++) key = min(key, __usad(e[n], x, (uint32_t)n));
-    return key;
-}
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
@@ -56,8 +41,8 @@ __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (
 //   * S' is bilinear inside a tile, so a stream is (S, step) at one pixel plus three constants, all in the ring Z/2^16 (the true
 //     S' lies in [0, 65280], so the ring value is exact): rows are walked in serpentine order with one packed subtract per pixel.
 //   * D = S' - 256*cur is formed with signed saturation on operands biased by -32768 (pixel bytes ^ 0x80, S' ^ 0x8000); the
-//     bounds of the tests are at most 256*rf + 255 <= 30975 for rf <= 120 (the launcher routes larger rejectFactors to
-//     yk_encode_kernel), so a saturated D compares like the true D.  Only min D / max D per stream are tracked.
+//     bounds of the tests are at most 256*rf + 255 = 16639 for the largest rejectFactor the C-ABI admits (64), well inside
+//     int16, so a saturated D compares like the true D.  Only min D / max D per stream are tracked.
 typedef short y2s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short y2u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ y2u2 y2_u2(uint32_t w) { return __builtin_bit_cast(y2u2, w); }
@@ -65,7 +50,6 @@ __device__ __forceinline__ y2s2 y2_s2(y2u2 v) { return __builtin_bit_cast(y2s2, 
 __device__ __forceinline__ y2u2 y2_splat(int v) { const unsigned short t = (unsigned short)v; return (y2u2){ t, t }; }
 __device__ __forceinline__ y2s2 y2_splats(int v) { const short t = (short)v; return (y2s2){ t, t }; }
 #define YK2_LATN 85                                                      // 17 x 5 lattice points (every 4th pixel incl. the halo) per strip
-#define YK2_RFMAX 120
 
 template <int SX, int SY>
 __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy, const int lane,
@@ -171,6 +155,67 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     }
 }
 
+// ---- quantiser table: for every rangeDecode R (32..255) and every offset o = v - BN (-2..255) the index and minDiff of the first
+// nearest entry of the six LUTs BN + K[R][mode][i], K = trunc(curve * R) (DynamicTile::buildTable, EncoderContext.cpp:662-696, and
+// the `<` scan of GetTileDynamic_Y, :873-881).  Row = 16 bytes: minDiff of modes 0..3 | minDiff of modes 4, 5 | six index nibbles | 0.
+#define YK2_QROWS 258
+#define YK2_QR0 32
+#define YK2_QNR 224
+__global__ void yk_qtab_kernel(uint4* tab) {
+    __shared__ int K[6][16];
+    const int R = YK2_QR0 + (int)blockIdx.x, t = threadIdx.x;
+    if (t < 96) { const int m = t >> 4, i = t & 15; K[m][i] = __float2int_rz(__fmul_rn(c_curve2[m][i], (float)R)); }
+    __syncthreads();
+    if (t < YK2_QROWS) {
+        const int o = t - 2;
+        uint32_t md03 = 0, md45 = 0, idx = 0;
+        for (int m = 0; m < 6; m++) {
+            const int cnt = m < 3 ? 16 : 8;
+            int best = 1 << 30, bi = 0;
+            for (int n = 0; n < cnt; n++) { const int d = abs(K[m][n] - o); if (d < best) { best = d; bi = n; } }
+            best = min(best, 255);                                       // only offsets no tile can reach exceed a byte
+            if (m < 4) md03 |= (uint32_t)best << (8 * m); else md45 |= (uint32_t)best << (8 * (m - 4));
+            idx |= (uint32_t)bi << (4 * m);
+        }
+        tab[(size_t)blockIdx.x * YK2_QROWS + t] = make_uint4(md03, md45, idx, 0u);
+    }
+}
+
+// yk_selftest 3: for every (min, max) of a tile, the LUTs built the reference's way (float add of BN) equal BN + K[rangeDecode]
+// and every value of the tile finds, in the table, the entry a scan of those LUTs finds.
+__global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
+    const int mn = blockIdx.x, mx = threadIdx.x;
+    if (mx < mn) return;
+    const int min_ = min(mn, 224);
+    int diff = mx - min_; if (diff < 16) diff = 16;
+    const int base = (min_ * 63 + 112) / 224;
+    const int BN = (base * 224) / 63;
+    const int d8 = max(diff, 32);
+    const int scale = 223 - BN;
+    const int dnum = (d8 - 32) * 127 + (scale - 1);
+    const int dist = (scale < 0) ? -dnum : dnum / scale;
+    const int R = (dist * scale) / 127 + 32;
+    int bad = 0;
+    if (R < YK2_QR0 || R >= YK2_QR0 + YK2_QNR || mn - BN < -2) { atomicAdd(mismatches, 1); return; }
+    for (int m = 0; m < 6; m++) {
+        const int cnt = m < 3 ? 16 : 8;
+        int L[16];
+        for (int i = 0; i < cnt; i++) {
+            L[i] = __float2int_rz(__fadd_rn((float)BN, __fmul_rn(c_curve2[m][i], (float)R)));
+            if (L[i] != BN + __float2int_rz(__fmul_rn(c_curve2[m][i], (float)R))) bad++;
+        }
+        for (int v = mn; v <= mx; v++) {
+            int best = 1 << 30, bi = 0;
+            for (int n = 0; n < cnt; n++) { const int d = abs(L[n] - v); if (d < best) { best = d; bi = n; } }
+            const uint4 row = tab[(size_t)(R - YK2_QR0) * YK2_QROWS + (v - BN + 2)];
+            const int md = m < 4 ? (row.x >> (8 * m)) & 255 : (row.y >> (8 * (m - 4))) & 255;
+            const int ix = (row.z >> (4 * m)) & 15;
+            if (md != best || ix != bi) bad++;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 #define YK2_RUN 16
 #define YK2_LUTW 84
 
@@ -187,12 +232,11 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     __shared__ uint32_t s_bm[24];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
-    // time), its mode sums, and the small-range tiles' 16 bins / 16 table entries per tile
-    __shared__ __attribute__((aligned(16))) uint32_t s_aux[672];
+    // time) and its mode sums
+    __shared__ __attribute__((aligned(16))) uint32_t s_aux[432];
     uint32_t* const s_lat = s_aux;
     float (*const s_chain)[68] = reinterpret_cast<float (*)[68]>(s_aux);
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
-    uint32_t* const s_small = s_aux + 416;
 
     const int lane = threadIdx.x;
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
@@ -455,36 +499,36 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const int dnum = (d8 - 32) * 127 + (scale - 1);                  // see yk_encode.hip / yk_selftest 1
             const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
             const int rangeDecode = (dist * scale) / 127 + 32;
-            const float Rf = (float)rangeDecode, BNf = (float)BN;
-            // the four lanes of the tile build the 72 LUT entries: lane j4 takes entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit).
-            // The curves are non-decreasing and Rf > 0, so every LUT is sorted: the first nearest entry of a pixel lies in the
-            // quarter selected by the midpoints between quarters (ties go to the lower quarter, like the reference's first-min scan).
+            // The tile's six LUTs (4-bit: 16 entries + three quarter midpoints, 3-bit: 8 entries; stored << 8) in LDS.  Only the
+            // exact-order fallback and the test-only reconstruction (wantDst) read them: the per-pixel work goes through the
+            // quantiser table below.  Lane j4 of the tile builds entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit).
+            auto buildLut = [&]() {
+                const float Rf = (float)rangeDecode, BNf = (float)BN;
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                uint32_t L[5];
+                for (int m = 0; m < 3; m++) {
+                    uint32_t L[4];
 #pragma unroll
-                for (int k = 0; k < 5; k++)
-                    L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][min(j4 * 4 + k, 15)], Rf)));
-                *reinterpret_cast<uint4*>(&lut[m * 20 + j4 * 4]) = make_uint4(L[0] << 8, L[1] << 8, L[2] << 8, L[3] << 8);
-                if (j4 < 3) lut[m * 20 + 16 + j4] = (L[3] + L[4]) << 7;
-            }
+                    for (int k = 0; k < 4; k++)
+                        L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 4 + k], Rf)));
+                    *reinterpret_cast<uint4*>(&lut[m * 20 + j4 * 4]) = make_uint4(L[0] << 8, L[1] << 8, L[2] << 8, L[3] << 8);
+                }
 #pragma unroll
-            for (int m = 3; m < 6; m++) {
-                uint32_t L[2];
+                for (int m = 3; m < 6; m++) {
+                    uint32_t L[2];
 #pragma unroll
-                for (int k = 0; k < 2; k++)
-                    L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf)));
-                *reinterpret_cast<uint2*>(&lut[60 + (m - 3) * 8 + j4 * 2]) = make_uint2(L[0] << 8, L[1] << 8);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int k = 0; k < 2; k++)
+                        L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf)));
+                    *reinterpret_cast<uint2*>(&lut[60 + (m - 3) * 8 + j4 * 2]) = make_uint2(L[0] << 8, L[1] << 8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
 
-            // v<<8 per pixel and a FAST reciprocal (v_rcp_f32, <= 1 ulp): the screening sums below only need ~1e-7 relative
-            // accuracy per term; the exact terms (IEEE division) are recomputed in the rare fallback.
-            uint32_t vs[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) vs[k] = (uint32_t)y2_byte(pw[k], p) << 8;
+            // ---- nearest LUT entry per pixel and mode: ONE 12-byte row of the quantiser table (yk_qtab_kernel).  Every LUT is
+            // BN + K[rangeDecode][mode][i] (the float add never carries into the integer part: checked for every (min, max) by
+            // yk_selftest 3), so index and minDiff of a pixel depend only on rangeDecode and v - BN.  The table (0.9 MB) lives in
+            // L2 and, for the few rangeDecode values a strip meets, in the CU's vector cache.
             // The reference adds the 64 exact terms minDiff/v SEQUENTIALLY in float (:885) and, walking the modes in order, keeps
             // mode m when err_m <= best (:897).  Any summation order of n <= 64 non-negative floats is within gamma_63 = 3.76e-6
             // (relative) of the exact sum and md*rcp(v) is within 2.5e-7 of the correctly rounded quotient, so a screening sum T
@@ -492,139 +536,82 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             // comparisons is therefore decided with certainty when the two sums are separated by 2e-5, or tie exactly with
             // identical per-pixel minDiffs (then the reference's sums are identical too: the later mode wins), or are both
             // exactly 0 (all terms 0).  Any other case (rare) flags the tile for exact re-summation in the reference's order.
-            // minDiff fits a byte: a LUT entry of 256 needs min >= 223, hence |256 - v| <= 33.
-            int bestMode = -1; float bestT = 0.0f;
-            uint32_t cLo = 0, cHi = 0;
-            bool amb = false;
-            // Tiles whose valid pixels span at most 16 values (flat areas, mild noise: most of a natural image) do not search per
-            // pixel: the tile's four lanes search the 16 possible values once per mode (4 each), the mode sums come from a 16-bin
-            // histogram (sum over bins of count * minDiff / v), and only the winning mode's table is applied to the pixels.
-            // Wave-uniform choice: taken when every live tile of the strip qualifies for this plane.
-#ifdef YK2_NO_SMALL
-            const bool smallWave = false;
-#else
-            const bool smallWave = (__ballot(valid && (mx - mn) > 15) == 0ULL) && !(P.ablate & (4 | 32));
-#endif
-            if (!smallWave) {
-                float rv[16];
+            const uint32_t qrow = (uint32_t)(((rangeDecode - YK2_QR0) * YK2_QROWS + 2 - BN) * 16);   // byte offset of the row of v = 0, modulo 2^32 (rows of the tile's own values, v >= BN - 2, are never negative)
+            float sm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+            uint32_t iw[16];                                                 // index nibbles of the six modes, per pixel
+            if (valid && !(P.ablate & 4)) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const int v = y2_byte(pw[k], p);
-                    rv[k] = (valid && v != 0) ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // r = 0 -> the term is exactly +0 (skipped pixel)
+                    const uint32_t v = (uint32_t)y2_byte(pw[k], p);
+                    const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
+                    const uint32_t m03 = row[0], m45 = row[1];
+                    iw[k] = row[2];
+                    const float rv = v ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // v == 0: the term is skipped (:884)
+                    sm[0] = __fmaf_rn((float)(m03 & 255u), rv, sm[0]);
+                    sm[1] = __fmaf_rn((float)((m03 >> 8) & 255u), rv, sm[1]);
+                    sm[2] = __fmaf_rn((float)((m03 >> 16) & 255u), rv, sm[2]);
+                    sm[3] = __fmaf_rn((float)(m03 >> 24), rv, sm[3]);
+                    sm[4] = __fmaf_rn((float)(m45 & 255u), rv, sm[4]);
+                    sm[5] = __fmaf_rn((float)((m45 >> 8) & 255u), rv, sm[5]);
                 }
-                uint32_t bMd[4] = { 0, 0, 0, 0 };
-#pragma unroll
-                for (int m = 0; m < 6; m++) {
-                    if (m >= P.startMode && !(P.ablate & 4)) {
-                        // key = (minDiff << 8) | index of the first nearest entry (:873-881): v_sad_u32(LUT<<8, v<<8, n) = (|LUT-v| << 8) + n
-                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
-                        uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
-                        if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
-                        else {
-                            const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
-                            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
-                        }
-                        float s = 0.0f;
-                        uint32_t mLo = 0, mHi = 0, mMd[4] = { 0, 0, 0, 0 };
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const uint32_t x = vs[k];
-                            const uint32_t key = (m < 3) ? y2_search16(lm, H1, H2, H3, x) : y2_search8(e, x);
-                            // pixel k's index nibble / minDiff byte enter at the top and shift down: after 8 (4) pixels pixel 0 sits lowest
-                            if (k < 8) mLo = __builtin_amdgcn_alignbit(key, mLo, 4); else mHi = __builtin_amdgcn_alignbit(key, mHi, 4);
-                            mMd[k >> 2] = __builtin_amdgcn_perm(key, mMd[k >> 2], 0x05030201u);
-                            s = __fmaf_rn((float)((key >> 8) & 255u), rv[k], s);
-                        }
-                        s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
-                        bool take;
-                        if (bestMode < 0) take = true;
-                        else if (__fmul_rn(s, 1.00002f) < bestT) take = true;                    // surely smaller
-                        else if (__fmul_rn(bestT, 1.00002f) < s) take = false;                   // surely larger
-                        else if (s == bestT) {
-                            if (s == 0.0f) take = true;                                          // both exactly zero
-                            else {
-                                const bool same = !valid || (mMd[0] == bMd[0] && mMd[1] == bMd[1] && mMd[2] == bMd[2] && mMd[3] == bMd[3]);
-                                const bool tileSame = (__ballot(!same) & (0x33ULL << l00)) == 0ULL;   // the tile's four lanes are active together
-                                take = true;
-                                if (!tileSame) amb = true;
-                            }
-                        } else { take = s <= bestT; amb = true; }
-                        if (take) { bestMode = m; bestT = s; cLo = mLo; cHi = mHi; bMd[0] = mMd[0]; bMd[1] = mMd[1]; bMd[2] = mMd[2]; bMd[3] = mMd[3]; }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                           // keep the modes sequential: bounds the live registers
-                }
-            
             } else {
-                uint32_t* hb = &s_small[tw * 16];
-                *reinterpret_cast<uint4*>(&s_small[lane * 4]) = make_uint4(0, 0, 0, 0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (valid) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) atomicAdd(&hb[y2_byte(pw[k], p) - mn], 1u);
+                for (int k = 0; k < 16; k++) iw[k] = 0;
+            }
+            int bestMode = -1; float bestT = 0.0f;
+            bool amb = false;
+            uint32_t ties = 0;                                               // bit m: mode m tied with the best so far (bits 8+3m..: that mode)
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                if (m >= P.startMode) {
+                    float t = sm[m];
+                    t = __fadd_rn(t, __shfl_xor(t, 1)); t = __fadd_rn(t, __shfl_xor(t, 4));
+                    bool take;
+                    if (bestMode < 0) take = true;
+                    else if (__fmul_rn(t, 1.00002f) < bestT) take = true;                        // surely smaller
+                    else if (__fmul_rn(bestT, 1.00002f) < t) take = false;                       // surely larger
+                    else if (t == bestT) {
+                        take = true;                                                             // both exactly zero, or identical minDiffs: checked below
+                        if (t != 0.0f) ties |= (1u << m) | ((uint32_t)bestMode << (8 + 3 * m));
+                    } else { take = t <= bestT; amb = true; }
+                    if (take) { bestMode = m; bestT = t; }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint4 cq = *reinterpret_cast<const uint4*>(&hb[j4 * 4]);              // this lane's four bins: values mn + 4*j4 .. +3
-                const uint32_t cnt4[4] = { cq.x, cq.y, cq.z, cq.w };
-                float wgt[4]; uint32_t xs[4], present = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int v = mn + j4 * 4 + i;
-                    xs[i] = (uint32_t)v << 8;
-                    wgt[i] = (cnt4[i] && v != 0) ? __fmul_rn((float)cnt4[i], __builtin_amdgcn_rcpf((float)v)) : 0.0f;   // v == 0: skipped pixel (:884)
-                    present |= cnt4[i] ? (0xFFu << (8 * i)) : 0u;
-                }
-                uint32_t bKey[4] = { 0, 0, 0, 0 }, bMdT = 0;
-#pragma unroll
-                for (int m = 0; m < 6; m++) {
-                    if (m >= P.startMode) {
-                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
-                        uint32_t e[8], H1 = 0, H2 = 0, H3 = 0;
-                        if (m < 3) { const uint4 t = *reinterpret_cast<const uint4*>(lm + 16); H1 = t.x; H2 = t.y; H3 = t.z; }
-                        else {
-                            const uint4 a = *reinterpret_cast<const uint4*>(lm), b = *reinterpret_cast<const uint4*>(lm + 4);
-                            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
-                        }
-                        uint32_t key[4], mdT = 0; float s = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            key[i] = (m < 3) ? y2_search16(lm, H1, H2, H3, xs[i]) : y2_search8(e, xs[i]);
-                            mdT |= ((key[i] >> 8) & 255u) << (8 * i);
-                            s = __fmaf_rn((float)((key[i] >> 8) & 255u), wgt[i], s);
-                        }
-                        mdT &= present;                                          // bins no pixel falls in do not take part in the tie test
-                        s = __fadd_rn(s, __shfl_xor(s, 1)); s = __fadd_rn(s, __shfl_xor(s, 4));
-                        bool take;
-                        if (bestMode < 0) take = true;
-                        else if (__fmul_rn(s, 1.00002f) < bestT) take = true;
-                        else if (__fmul_rn(bestT, 1.00002f) < s) take = false;
-                        else if (s == bestT) {
-                            if (s == 0.0f) take = true;
-                            else {
-                                const bool tileSame = (__ballot(mdT != bMdT) & (0x33ULL << l00)) == 0ULL;
-                                take = true;
-                                if (!tileSame) amb = true;
-                            }
-                        } else { take = s <= bestT; amb = true; }
-                        if (take) { bestMode = m; bestT = s; bMdT = mdT; bKey[0] = key[0]; bKey[1] = key[1]; bKey[2] = key[2]; bKey[3] = key[3]; }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the winning mode's table -> the pixels' index nibbles
-                __builtin_amdgcn_wave_barrier();
-                *reinterpret_cast<uint4*>(&hb[j4 * 4]) = make_uint4(bKey[0], bKey[1], bKey[2], bKey[3]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (bestMode < 0) bestMode = 5;
+            // exact ties: the later mode wins when the two modes' minDiffs agree on every valid pixel of the tile (identical sums in
+            // the reference too); otherwise the tile is ambiguous.  Rare enough to re-read the rows (cache hits) instead of keeping them.
+            if (__ballot(ties != 0u && tileLive) != 0ULL) {
+                uint32_t differ = 0;
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        const uint32_t key = hb[y2_byte(pw[k], p) - mn];
-                        if (k < 8) cLo = __builtin_amdgcn_alignbit(key, cLo, 4); else cHi = __builtin_amdgcn_alignbit(key, cHi, 4);
+                        const uint32_t v = (uint32_t)y2_byte(pw[k], p);
+                        const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
+                        const unsigned long long X = ((unsigned long long)row[1] << 32) | row[0];
+#pragma unroll
+                        for (int m = 1; m < 6; m++) {
+                            const uint32_t b = (ties >> (8 + 3 * m)) & 7u;
+                            differ |= ((((uint32_t)(X >> (8 * m)) ^ (uint32_t)(X >> (8 * b))) & 255u) ? 1u : 0u) << m;
+                        }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                differ &= ties;
+                if ((__ballot(differ != 0u) & (0x33ULL << l00)) != 0ULL) amb = true;     // the tile's four lanes are active together
             }
-            if (bestMode < 0) bestMode = 5;                                  // only reachable with the timing-only ablation flag 4
+            uint32_t cLo = 0, cHi = 0;
+            {
+                const uint32_t sh = 4u * (uint32_t)bestMode;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    // pixel k's index nibble enters at the top and shifts down: after 8 pixels pixel 0 sits lowest
+                    const uint32_t code = iw[k] >> sh;
+                    if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
+                }
+            }
             if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
             unsigned long long ambMask = __ballot(amb && tileLive);
+            const bool needLut = (ambMask != 0ULL) || P.wantDst;
+            if (needLut) buildLut();
             while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
                 const int al = __ffsll((long long)ambMask) - 1;              // a lane of the tile
                 const int ac = al & 15;
@@ -641,7 +628,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                                 const int k = r * 4 + i;
                                 uint32_t v4 = 0;
 #pragma unroll
-                                for (int kk = 0; kk < 16; kk++) v4 = (kk == k) ? vs[kk] : v4;
+                                for (int kk = 0; kk < 16; kk++) v4 = (kk == k) ? ((uint32_t)y2_byte(pw[kk], p) << 8) : v4;
                                 uint32_t key = 0xFFFFFFFFu;
                                 for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], v4, (uint32_t)n));
                                 const int v = (int)(v4 >> 8);
@@ -678,7 +665,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         uint32_t key = 0xFFFFFFFFu;
-                        for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], vs[k], (uint32_t)n));
+                        for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], (uint32_t)y2_byte(pw[k], p) << 8, (uint32_t)n));
                         if (k < 8) cLo |= (key & 15u) << (4 * k); else cHi |= (key & 15u) << (4 * (k - 8));
                     }
                 }
@@ -713,7 +700,29 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 
 }
 
+// one quantiser table per device and process, built on first use
+static uint8_t* g_qtab[64] = {};
+static std::mutex g_qtabMu;
+int yk_qtab_get(yk_ctx* c) {
+    std::lock_guard<std::mutex> guard(g_qtabMu);
+    if (c->device < 0 || c->device >= 64) return yk_fail(c, YK_ERR_BAD_ARG, "device index");
+    if (!g_qtab[c->device]) {
+        uint8_t* t = nullptr;
+        YK_HIP(c, hipMalloc(&t, (size_t)YK2_QNR * YK2_QROWS * 16));
+        hipLaunchKernelGGL(yk_qtab_kernel, dim3(YK2_QNR), dim3(320), 0, c->stream, reinterpret_cast<uint4*>(t));
+        YK_HIP(c, hipGetLastError());
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        g_qtab[c->device] = t;
+    }
+    c->qtab = g_qtab[c->device];
+    return YK_OK;
+}
+void yk_selftest_qtab_launch(yk_ctx* c, int* mismatches) {
+    hipLaunchKernelGGL(yk_selftest_qtab_kernel, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(c->qtab), mismatches);
+}
+
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
+    if (!P.qtab) return yk_fail(c, YK_ERR_STATE, "quantiser table missing");
     const int nB = P.xBB64 * P.yBB64 * P.nFrames, group = 8 * YK2_RUN;
     // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
     YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
