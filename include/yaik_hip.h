@@ -190,12 +190,16 @@ int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
  * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches
  * which = 1: floor((n + 0.5) * rcp(scale)) == n / scale for DiffRangeEncode's operands (EncoderContext.cpp:604-623)
- * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391) */
+ * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391)
+ * which = 3: the quantiser table of the fused kernel: for every (min, max) of a tile the LUTs of DynamicTile::buildTable
+ *            (EncoderContext.cpp:625-699) equal BN + K[rangeDecode], and every value in [min, max] finds in the table the index
+ *            and minDiff the first-minimum scan of GetTileDynamic_Y (:873-881) finds in those LUTs */
 int yk_selftest(yk_ctx* c, int which, int* result);
 /* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
- * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the LUT search, 8 = skip the error sums.
- * Two flags only select a code path and leave the results exact (used by the parity tests): 16 = re-sum every tile in the
- * reference's sequential order, 32 = never take the small-range (histogram) path of the range quantiser. */
+ * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the nearest-entry lookups (table gathers; LUT search in
+ * the first-generation kernel), 8 = skip the error sums (first-generation kernel).
+ * One flag only selects a code path and leaves the results exact (used by the parity tests): 16 = re-sum every tile in the
+ * reference's sequential order. */
 int yk_set_ablation(yk_ctx* c, int flags);
 /* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = lane per 4x4 cell, 1 = lane per pixel row.
  * Both produce identical results; kept selectable for A/B timing and as a cross-check in the tests. */

@@ -53,25 +53,6 @@ def test_exact_resummation_path_bit_exact(oracle_built, case):
         e.close()
 
 
-@pytest.mark.parametrize("case", ["synth256x4", "mixed128x4", "smooth128"])
-def test_per_pixel_search_path_bit_exact(oracle_built, case):
-    """kernel v2 quantises strips whose live tiles span <= 16 values through a 16-bin histogram and per-value tables; flag 32
-    forces the per-pixel search for every tile instead, and the result must be the same bit-exact streams."""
-    from yaik_amd._lib import lib
-    from yaik_amd.encoder import HipTileEncoder
-    planes = {"synth256x4": lambda: synth_planes(256, n_planes=4), "mixed128x4": lambda: edge_image(128, 128, "mixed", 4),
-              "smooth128": lambda: edge_image(128, 128, "smooth", 3)}[case]()
-    e = HipTileEncoder(0)
-    try:
-        lib().yk_set_kernel_version(e._h, 2)
-        lib().yk_set_ablation(e._h, 32)
-        for m3 in (False, True):
-            bad = compare_encode(planes, e, m3)
-            assert not bad, bad
-    finally:
-        e.close()
-
-
 @pytest.mark.parametrize("rf", [0, 1, 2, 5, 9, 40, 64])
 def test_other_reject_factors_bit_exact(hip, oracle_built, rf):
     """FittingQuadSmooth's rejectFactor is an argument of the operator (the shipped encoder always passes 3): the range tests on

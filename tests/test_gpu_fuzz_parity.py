@@ -1,5 +1,5 @@
 """Randomised parity: many small images whose 8x8 tiles are drawn from the regimes where the encoder's shortcuts change
-behaviour — ranges straddling the small-range path's limit (15/16), values >= 223 (LUT entries reach 256), zeros (terms the
+behaviour — ranges straddling 15/16 and 32 (where rangeDecode leaves its minimum), values >= 223 (LUT entries reach 256), zeros (terms the
 reference skips), two- and three-level tiles (exact ties between modes), gradients with +-3/+-4 deviations (the accept
 boundary of FittingQuadSmooth), random alpha masks per 16x16 tile.  HIP (both kernel generations) vs the oracle, bit-exact."""
 import numpy as np

@@ -11,7 +11,7 @@ planes = synth_planes_torch(W, n_planes=4, device="cuda")
 enc = HipTileEncoder(0)
 enc.set_image(planes)
 enc.alpha_reject(); enc.alpha_finish(None)
-names = {0: "full", 1: "no range", 2: "no gradient", 3: "load+stage only", 4: "no LUT search"}
+names = {0: "full", 1: "no range", 2: "no gradient", 3: "load+stage only", 4: "no table gathers"}
 for ver in (1, 2):
     lib().yk_set_kernel_version(enc._h, ver)
     for flags, name in names.items():
