@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
+    __shared__ float s_rcp[256];                                            // fast reciprocal of a pixel value; [0] = 0 (skipped term, :884)
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
     // time) and its mode sums
     __shared__ __attribute__((aligned(16))) uint32_t s_aux[432];
@@ -479,6 +480,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     } else {
         uint32_t* lut = &s_lut[tw][0];
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __builtin_amdgcn_rcpf((float)v) : 0.0f; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int p = 0; p < 3; p++) {
             // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
             int mn = 99999999, mx = -99999999;
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
                     const uint32_t m03 = row[0], m45 = row[1];
                     iw[k] = row[2];
-                    const float rv = v ? __builtin_amdgcn_rcpf((float)v) : 0.0f;   // v == 0: the term is skipped (:884)
+                    const float rv = s_rcp[v];                                   // v_rcp_f32 is a quarter-rate op: 16 per plane add up
                     sm[0] = __fmaf_rn((float)(m03 & 255u), rv, sm[0]);
                     sm[1] = __fmaf_rn((float)((m03 >> 8) & 255u), rv, sm[1]);
                     sm[2] = __fmaf_rn((float)((m03 >> 16) & 255u), rv, sm[2]);
