@@ -27,6 +27,23 @@ def edge_image(w: int, h: int, kind: str, n_planes: int = 3, seed: int = 7) -> n
         rgb = np.where(m, rng.integers(0, 256, (3, h, w)), rgb)
         m2 = ((x // 8 + y // 8) % 5) == 0
         rgb = np.where(m2, np.clip(rgb + rng.integers(-6, 7, (3, h, w)), 0, 255), rgb)
+    elif kind == "photo":
+        # photo-like: smooth illumination + hard-edged objects + band-limited texture of varying strength + mild sensor noise:
+        # 8x8 tiles with every span from 0 to ~150, i.e. every rangeDecode regime of DynamicTile::buildTable
+        fx, fy = x / w, y / h
+        chans = []
+        for c in range(3):
+            base = 110 + 70 * np.sin(2.1 * fx + 0.7 * c) * np.cos(1.7 * fy - 0.4 * c) + 40 * (fx - fy)
+            tex = np.zeros_like(base)
+            for k in range(1, 6):
+                tex += (1.0 / k) * np.sin(2 * np.pi * ((5.0 * k + 2 * c) * fx * (w / 64) + (4.0 * k + c) * fy * (h / 64)) + k)
+            strength = 40 * np.clip(np.sin(3 * np.pi * fx) * np.sin(2 * np.pi * fy), 0, None) ** 2
+            img = base + strength * tex
+            for (x0, y0, x1, y1, v) in ((0.1, 0.15, 0.3, 0.45, 60), (0.55, 0.2, 0.9, 0.35, -50), (0.35, 0.6, 0.7, 0.9, 35)):
+                img = img + ((fx > x0) & (fx < x1) & (fy > y0) & (fy < y1)) * (v + 8 * c)
+            img = img + rng.normal(0, 2.5, (h, w)) * (fy > 0.5)
+            chans.append(np.round(img))
+        rgb = np.stack(chans)
     elif kind == "twocolor":
         a = rng.integers(0, 256, 3); b = rng.integers(0, 256, 3)
         sel = ((x * 7 + y * 13) // 5) % 2

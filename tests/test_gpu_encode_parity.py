@@ -27,10 +27,17 @@ def test_synth_bit_exact(hip, oracle_built, size, npl, m3):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("kind", ["flat", "noise", "ramp", "smooth", "mixed", "white", "dark", "twocolor"])
+@pytest.mark.parametrize("kind", ["flat", "noise", "ramp", "smooth", "mixed", "white", "dark", "twocolor", "photo"])
 @pytest.mark.parametrize("wh,npl", [((64, 64), 3), ((128, 128), 4), ((72, 40), 3), ((200, 136), 3), ((256, 256), 4)])
 def test_edge_images_bit_exact(hip, oracle_built, kind, wh, npl):
     bad = compare_encode(edge_image(wh[0], wh[1], kind, npl), hip, False)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("m3", [False, True])
+def test_photo_like_1024_bit_exact(hip, oracle_built, m3):
+    """Textured content: tiles of every span, i.e. every rangeDecode slab of the quantiser table, incl. exact ties between modes."""
+    bad = compare_encode(edge_image(1024, 1024, "photo", 4, seed=3), hip, m3)
     assert not bad, bad
 
 

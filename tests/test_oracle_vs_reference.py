@@ -18,6 +18,8 @@ CASES = {
     "dark64_rgb": lambda: edge_image(64, 64, "dark", 3),
     "twocolor256_rgba": lambda: edge_image(256, 256, "twocolor", 4),
     "mixed200x136_rgb": lambda: edge_image(200, 136, "mixed", 3),
+    "photo256_rgba": lambda: edge_image(256, 256, "photo", 4),
+    "photo192x128_rgb": lambda: edge_image(192, 128, "photo", 3, seed=11),
 }
 
 
