@@ -217,6 +217,15 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
 }
 
 #define YK2_RUN 16
+// -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
+// five points into a device array that yk_debug_wave_times copies out.
+#ifdef YK2_TIMING
+__device__ unsigned long long g_y2_times[65536 * 12];
+#define YK2_PROBE(i) do { if ((i) == 0 && lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 12 + 10] = 0; g_y2_times[(size_t)unit * 12 + 11] = 0; } if (lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 12 + 2 * (i)] = __builtin_amdgcn_s_memtime(); g_y2_times[(size_t)unit * 12 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_y2_times), sizeof(g_y2_times)); }
+#else
+#define YK2_PROBE(i) do { } while (0)
+#endif
 #define YK2_LUTW 84
 
 __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams P) {
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
-    __shared__ float s_rcp[256];                                            // fast reciprocal of a pixel value; [0] = 0 (skipped term, :884)
+    __shared__ float s_rcp[256];                                            // RN(1 / pixel value); [0] = 0 (skipped term, :884)
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
     // time) and its mode sums
     __shared__ __attribute__((aligned(16))) uint32_t s_aux[432];
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const int BY = L / P.xBB64, BX = L - BY * P.xBB64;
     const int w = P.w, h = P.h;
 
+    YK2_PROBE(0);
     if (lane < 24) s_bm[lane] = 0;
     s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
     if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         if (hr >= 0 && hr < 17) s_pix[hr * LS + 64] = hcol;
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
+    YK2_PROBE(1);
 
     // ---- corner lattice (every 4th pixel, 17 x 5 points incl. the halo): Round6 / Round6P of the three channels at once (SWAR)
     // and the five packed streams of y2_grad_pass
@@ -401,6 +412,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
     // strip's tiles into whole bytes of the block's words except 16x16 (4 bits per strip), which is OR-ed into a pre-zeroed map.
     __syncthreads();                                                         // fence: s_bm complete; s_pix dead, its LDS becomes s_lut
+    YK2_PROBE(2);
     if (lane == 0) {
         const int i64 = BY * P.xBB64 + BX;
         const uint32_t nib = (s_bm[0] >> (4 * wave)) & 0xFu;
@@ -421,6 +433,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
         }
     }
+    YK2_PROBE(3);
     // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
     if (boundsP) {
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         uint32_t* lut = &s_lut[tw][0];
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __builtin_amdgcn_rcpf((float)v) : 0.0f; }
+        for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __fdiv_rn(1.0f, (float)v) : 0.0f; }   // correctly rounded: the exact path needs that
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int p = 0; p < 3; p++) {
             // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
                     const uint32_t m03 = row[0], m45 = row[1];
                     iw[k] = row[2];
-                    const float rv = s_rcp[v];                                   // v_rcp_f32 is a quarter-rate op: 16 per plane add up
+                    const float rv = s_rcp[v];                                   // a table: v_rcp_f32 is a quarter-rate op, 16 per plane add up
                     sm[0] = __fmaf_rn((float)(m03 & 255u), rv, sm[0]);
                     sm[1] = __fmaf_rn((float)((m03 >> 8) & 255u), rv, sm[1]);
                     sm[2] = __fmaf_rn((float)((m03 >> 16) & 255u), rv, sm[2]);
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 if ((__ballot(differ != 0u) & (0x33ULL << l00)) != 0ULL) amb = true;     // the tile's four lanes are active together
             }
             uint32_t cLo = 0, cHi = 0;
-            {
+            {                                                                // the lane's 16 index nibbles of the best mode, pixel 0 lowest
                 const uint32_t sh = 4u * (uint32_t)bestMode;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -614,32 +627,42 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
             if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
             unsigned long long ambMask = __ballot(amb && tileLive);
-            const bool needLut = (ambMask != 0ULL) || P.wantDst;
-            if (needLut) buildLut();
+#ifdef YK2_TIMING
+            if (lane == 0 && unit < 65536 && ambMask) { g_y2_times[(size_t)unit * 12 + 10] += (unsigned long long)__popcll(ambMask) / 4; g_y2_times[(size_t)unit * 12 + 11] += 1; }
+#endif
+            if (P.wantDst) buildLut();
             while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
                 const int al = __ffsll((long long)ambMask) - 1;              // a lane of the tile
                 const int ac = al & 15;
                 const int a00 = al - ((ac >> 2) & 1) * 4 - (ac & 1);        // top-left lane of that tile
                 ambMask &= ~(0x33ULL << a00);
                 if (l00 == a00) {                                            // the four lanes of the tile publish their exact terms in pixel order
-                    for (int m = P.startMode; m < 6; m++) {
-                        const uint32_t* lm = lut + (m < 3 ? m * 20 : 60 + (m - 3) * 8);
-                        const int cnt = m < 3 ? 16 : 8;
-                        for (int r = 0; r < 4; r++) {
-                            float qv[4];
 #pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const int k = r * 4 + i;
-                                uint32_t v4 = 0;
+                    for (int r = 0; r < 4; r++) {                            // four rows in flight at a time: this path is rare, registers matter more
+                        uint32_t m03[4], m45[4];
 #pragma unroll
-                                for (int kk = 0; kk < 16; kk++) v4 = (kk == k) ? ((uint32_t)y2_byte(pw[kk], p) << 8) : v4;
-                                uint32_t key = 0xFFFFFFFFu;
-                                for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], v4, (uint32_t)n));
-                                const int v = (int)(v4 >> 8);
-                                qv[i] = (valid && v != 0) ? __fdiv_rn((float)(int)(key >> 8), (float)v) : 0.0f;      // divss (:885)
+                        for (int i = 0; i < 4; i++) {
+                            m03[i] = 0; m45[i] = 0;
+                            if (valid) {
+                                const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + (uint32_t)y2_byte(pw[r * 4 + i], p) * 16u));
+                                m03[i] = row[0]; m45[i] = row[1];
                             }
-                            *reinterpret_cast<float4*>(&s_chain[m][(cyl * 4 + r) * 8 + cxl * 4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
                         }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t v = (uint32_t)y2_byte(pw[r * 4 + i], p);
+                            // minDiff / v as the reference's divss (:885): correctly rounded reciprocal + one correction step (yk_selftest 0);
+                            // a skipped pixel (covered, masked or v == 0) contributes +0, which leaves a float sum unchanged
+                            const float fv = (float)v, rr = valid ? s_rcp[v] : 0.0f;
+                            float* dst = &s_chain[0][(cyl * 4 + r) * 8 + cxl * 4 + i];
+                            dst[0 * 68] = yk_div_exact((float)(m03[i] & 255u), fv, rr);
+                            dst[1 * 68] = yk_div_exact((float)((m03[i] >> 8) & 255u), fv, rr);
+                            dst[2 * 68] = yk_div_exact((float)((m03[i] >> 16) & 255u), fv, rr);
+                            dst[3 * 68] = yk_div_exact((float)(m03[i] >> 24), fv, rr);
+                            dst[4 * 68] = yk_div_exact((float)(m45[i] & 255u), fv, rr);
+                            dst[5 * 68] = yk_div_exact((float)((m45[i] >> 8) & 255u), fv, rr);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -648,6 +671,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 if (lane < 6 && lane >= P.startMode) {                       // errorDist += minDiff / v in row-major pixel order (:885)
                     float s = 0.0f;
                     const float4* cp = reinterpret_cast<const float4*>(&s_chain[lane][0]);
+#pragma unroll
                     for (int k = 0; k < 16; k++) {
                         const float4 a = cp[k];
                         s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, a.x), a.y), a.z), a.w);
@@ -663,14 +687,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                         const float e = s_err[m];
                         if (e <= bestErr) { bestErr = e; bestMode = m; }
                     }
-                    const uint32_t* lm = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
-                    const int cnt = bestMode < 3 ? 16 : 8;
-                    cLo = 0; cHi = 0;
+                    const uint32_t sh = 4u * (uint32_t)bestMode;             // the index words are read again: they are not kept for this rare path
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        uint32_t key = 0xFFFFFFFFu;
-                        for (int n = 0; n < cnt; n++) key = min(key, __usad(lm[n], (uint32_t)y2_byte(pw[k], p) << 8, (uint32_t)n));
-                        if (k < 8) cLo |= (key & 15u) << (4 * k); else cHi |= (key & 15u) << (4 * (k - 8));
+                        uint32_t code = 0;
+                        if (valid) code = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + (uint32_t)y2_byte(pw[k], p) * 16u))[2] >> sh;
+                        if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -701,7 +723,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             __builtin_amdgcn_wave_barrier();
         }
     }
-
+    YK2_PROBE(4);
 }
 
 // one quantiser table per device and process, built on first use
