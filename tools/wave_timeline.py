@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 L = lib()
 L.yk_debug_wave_times.argtypes = [C.c_void_p]; L.yk_debug_wave_times.restype = C.c_int
-t = np.zeros((65536, 6, 2), np.uint64)
+t = np.zeros((65536, 8, 2), np.uint64)
 assert L.yk_debug_wave_times(t.ctypes.data) == 0
 clk = t[:, :5, 0].astype(np.int64); rt = t[:, :5, 1].astype(np.int64)
 rt0 = rt[:, 0].min()
@@ -62,3 +62,16 @@ print("ambiguous tile-planes per wave (exact re-summation): waves with any:", in
 for a, b in ((0, 0), (1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 999)):
     m = (amb_tiles >= a) & (amb_tiles <= b) & (k == 2) & kept
     if m.any(): print(f"  mild kept waves with {a}-{b} ambiguous tile-planes: {int(m.sum())}, mean range phase {np.diff(us[m], axis=1)[:, 3].mean():.1f} us")
+entry = (t[:, 6, 0].astype(np.int64) - rt0) / 100.0
+hw = t[:, 6, 1]
+slot = hw & np.uint64(0xFFFFFFFFFF)        # xcc | hw_id (wave, simd, cu, sh, se ...) identifies the hardware wave slot
+print(f"entry -> first probe (kernel arguments, unit arithmetic): mean {np.mean(us[:, 0] - entry):.2f} us")
+gaps = []
+for sid in np.unique(slot):
+    m = np.where(slot == sid)[0]
+    o = m[np.argsort(entry[m])]
+    g = entry[o][1:] - us[o, 4][:-1]
+    gaps.append(g)
+gaps = np.concatenate(gaps)
+print(f"hardware wave slots seen: {len(np.unique(slot))}; idle gap between a wave's last probe and the next wave's entry on the same slot: "
+      f"mean {gaps.mean():.2f} us, median {np.median(gaps):.2f}, p90 {np.percentile(gaps, 90):.2f}")

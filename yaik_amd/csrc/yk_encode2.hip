@@ -218,10 +218,10 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
 
 #define YK2_RUN 16
 // -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
-// five points into a device array that yk_debug_wave_times copies out.
+// five points, its entry time and its hardware slot (HW_ID, XCC_ID) into a device array that yk_debug_wave_times copies out.
 #ifdef YK2_TIMING
-__device__ unsigned long long g_y2_times[65536 * 12];
-#define YK2_PROBE(i) do { if ((i) == 0 && lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 12 + 10] = 0; g_y2_times[(size_t)unit * 12 + 11] = 0; } if (lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 12 + 2 * (i)] = __builtin_amdgcn_s_memtime(); g_y2_times[(size_t)unit * 12 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long g_y2_times[65536 * 16];
+#define YK2_PROBE(i) do { if ((i) == 0 && lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 16 + 10] = 0; g_y2_times[(size_t)unit * 16 + 11] = 0; g_y2_times[(size_t)unit * 16 + 12] = y2_t_entry; g_y2_times[(size_t)unit * 16 + 13] = ((unsigned long long)y2_xcc << 32) | y2_hwid; } if (lane == 0 && unit < 65536) { g_y2_times[(size_t)unit * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime(); g_y2_times[(size_t)unit * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_y2_times), sizeof(g_y2_times)); }
 #else
 #define YK2_PROBE(i) do { } while (0)
@@ -249,6 +249,10 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
 
     const int lane = threadIdx.x;
+#ifdef YK2_TIMING
+    const unsigned long long y2_t_entry = __builtin_amdgcn_s_memrealtime();
+    const unsigned y2_hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), y2_xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+#endif
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
     // taken in row-major runs of YK2_RUN blocks (4 strips each); XCD k gets a rotating run of every group of 8 runs, so the
     // halo column of a block and the halo row of a strip are lines a neighbour streams through the same L2 at about the same
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
             unsigned long long ambMask = __ballot(amb && tileLive);
 #ifdef YK2_TIMING
-            if (lane == 0 && unit < 65536 && ambMask) { g_y2_times[(size_t)unit * 12 + 10] += (unsigned long long)__popcll(ambMask) / 4; g_y2_times[(size_t)unit * 12 + 11] += 1; }
+            if (lane == 0 && unit < 65536 && ambMask) { g_y2_times[(size_t)unit * 16 + 10] += (unsigned long long)__popcll(ambMask) / 4; g_y2_times[(size_t)unit * 16 + 11] += 1; }
 #endif
             if (P.wantDst) buildLut();
             while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
