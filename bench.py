@@ -37,7 +37,8 @@ def main() -> int:
     ap.add_argument("--mode3", action="store_true", help="3-bpp range modes only (DynamicTileEncode mode3BitOnly)")
     ap.add_argument("--in-flight", type=int, default=2, help="frames per GPU kept in flight on separate handles/streams (a step = that many frames per "
                     "GPU).  Default 2: a stream of frames, where the HBM-bound alpha / pack kernels of one frame run under the VALU-bound fused "
-                    "kernel of the other (the fused kernels themselves do not overlap: each fills the chip); 1 = strictly one frame at a time")
+                    "kernel of the other (the fused kernels themselves take turns: yk_order_fused_after); 1 = strictly one frame at a time")
+    ap.add_argument("--free-overlap", action="store_true", help="with --in-flight > 1: do not order the fused kernels of the frames (they then share the chip)")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU held by ONE handle and encoded with one launch per kernel (yk_encode_batch): "
                     "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
@@ -108,8 +109,14 @@ def main() -> int:
     use_async = world > 1 and not rehearsal    # device-side hand-over to the communicator's stream (needs the payload in HBM)
     deferred = []                              # rehearsal only: (nbytes, sizes) of exports whose gather is launched under the next step
 
+    # frames of at least four rounds of strip-waves: the fused kernels of the frames in flight take turns (two of them sharing the chip
+    # only slow each other down); smaller frames need each other's waves to fill the chip and stay unordered
+    ordered = K > 1 and not BF and not args.graph and not args.free_overlap and W * W >= 8192 * 8192
+
     def step():
-        for e in encs:                         # no host synchronisation in here: K frames are in flight on K streams
+        for j, e in enumerate(encs):           # no host synchronisation in here: K frames are in flight on K streams
+            if ordered:
+                e.order_fused_after(encs[j - 1])   # alpha / compaction overlap the other frame's fused kernel; the fused kernels take turns
             if BF:
                 e.encode_batch(3, args.mode3)
             elif args.graph:
@@ -234,11 +241,11 @@ def main() -> int:
         roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
     elif args.graph:
         roofline["note"] = "--graph: kernel_ms is the whole frame (alpha stage + fused kernel + compaction replayed as one hipGraph)"
-    elif K == 2:
-        roofline["note"] = ("2 frames in flight: the fused kernels of the two frames run one after the other (each fills the chip); the alpha / pack "
-                            "intervals in other_kernels_ms include the time those stages queue behind the other frame's fused kernel")
-    elif K > 2:
-        roofline["note"] = f"{K} frames in flight: each kernel's duration includes the time it shares the chip with the other frame's kernels"
+    elif ordered:
+        roofline["note"] = (f"{K} frames in flight on {K} streams: the fused kernels take turns (yk_order_fused_after), the alpha / pack stages of one "
+                            "frame run under the fused kernel of another; their intervals in other_kernels_ms include the time they share the chip")
+    elif K >= 2:
+        roofline["note"] = f"{K} frames in flight, unordered: each kernel's duration includes the time it shares the chip with the other frames' kernels"
 
     result = {
         "metric": "Mpix/s tile encode (alpha reject + 7 gradient passes + 8x8 range quant), 8K RGBA",

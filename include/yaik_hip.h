@@ -111,6 +111,13 @@ int yk_bind_device_batch(yk_ctx* c, const int32_t* const frame0Planes[4], int st
 int yk_encode_batch(yk_ctx* c, int rejectFactor, int mode3BitOnly);
 int yk_select_frame(yk_ctx* c, int frame);
 
+/* ---- streams of frames on several handles (new) --------------------------------------------------------------------------
+ * With two handles (two streams) in flight the HBM-bound alpha / compaction kernels of one frame run under the fused kernel of
+ * the other.  Two fused kernels sharing the chip only slow each other down, so a caller that alternates handles can order them:
+ * the NEXT yk_encode_tiles of c launches its fused kernel after the fused kernel most recently launched on `other` has finished
+ * (a stream-wait on an event, no host synchronisation; the alpha stage and the compaction of c are not held back).  Same device. */
+int yk_order_fused_after(yk_ctx* c, const yk_ctx* other);
+
 /* gradient results (valid after yk_encode_tiles) -------------------------------------------------
  * swizzled 1-bit tile bitmap of pass p, byte-exact `pFillBitMap` (:3775-3777, bit rule :3801-3805,:4026;
  * size = HeaderGradientTile::getBitmapSwizzleSize/8, include/YAIK_private.h:278-286) */

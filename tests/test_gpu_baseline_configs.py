@@ -221,3 +221,34 @@ def test_batch_launch_equals_per_frame_results(oracle_built, size, npl, nf):
                 assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), (f, p)
     finally:
         e.close()
+
+
+def test_ordered_fused_kernels_on_two_handles_keep_every_frame_exact(oracle_built):
+    """Streams of frames on two handles with yk_order_fused_after (the fused kernels take turns, no host synchronisation in between):
+    every frame's streams equal the oracle's, whatever the interleaving."""
+    from oracle.pyoracle import PASSES, OracleEncoder
+    from yaik_amd.encoder import HipTileEncoder
+    from yaik_amd.synth import synth_planes
+    encs = [HipTileEncoder(0), HipTileEncoder(0)]
+    try:
+        host = [synth_planes(512, n_planes=4, seed=4000 + j) for j in range(2)]
+        for e, pl in zip(encs, host):
+            e.set_image(pl)
+        for rep in range(4):
+            for j, e in enumerate(encs):
+                e.order_fused_after(encs[j - 1])
+                e.alpha_reject(); e.alpha_finish(None)
+                e.encode(3, False, False)
+        for e, pl in zip(encs, host):
+            ora = OracleEncoder(pl)
+            mo, mh = ora.mip_prefilter(), e.alpha_result()
+            assert np.array_equal(mh["bounds"], mo["bounds"]) and np.array_equal(mh["bitmap"], mo["bitmap"])
+            for i, (sx, sy) in enumerate(PASSES):
+                assert np.array_equal(e.gradient_bitmap(i), ora.fitting_quad_smooth(sx, sy)[1]), i
+            for p in range(3):
+                defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
+                d2, n2, nn2 = e.range_streams(p)
+                assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), p
+    finally:
+        for e in encs:
+            e.close()

@@ -53,6 +53,7 @@ SIGNATURES = {
     "yk_bind_device_batch": (C.c_int, [vp, C.POINTER(vp), C.c_int, sz]),
     "yk_encode_batch": (C.c_int, [vp, C.c_int, C.c_int]),
     "yk_select_frame": (C.c_int, [vp, C.c_int]),
+    "yk_order_fused_after": (C.c_int, [vp, vp]),
     "yk_gradient_bitmap_bytes": (sz, [vp, C.c_int]),
     "yk_gradient_bitmap": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_gradient_bitmap_device": (vp, [vp, C.c_int]),

@@ -359,6 +359,7 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     }
     hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];
     if (!c->evAlphaInCur) { YK_HIP(c, hipEventRecord(ev[0], c->stream)); YK_HIP(c, hipEventRecord(ev[1], c->stream)); }   // no alpha stage: zero-length interval
+    if (c->fusedAfter) { YK_HIP(c, hipStreamWaitEvent(c->stream, c->fusedAfter, 0)); c->fusedAfter = nullptr; }   // yk_order_fused_after
     YK_HIP(c, hipEventRecord(ev[2], c->stream));
     int rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, wantDst); if (rc) return rc;
     YK_HIP(c, hipEventRecord(ev[3], c->stream));
@@ -368,6 +369,13 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;       // the oldest sets were overwritten
     c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->nextCornerPass = 0; c->r1Ready = false;
+    return YK_OK;
+}
+
+int yk_order_fused_after(yk_ctx* c, const yk_ctx* other) {
+    if (!c || !other) return YK_ERR_BAD_ARG;
+    if (c->device != other->device) return yk_fail(c, YK_ERR_BAD_ARG, "yk_order_fused_after: handles of one device");
+    c->fusedAfter = other->evHead ? other->evRing[(other->evHead - 1) % YK_EV_RING][3] : nullptr;
     return YK_OK;
 }
 

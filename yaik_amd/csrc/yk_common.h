@@ -82,6 +82,7 @@ struct yk_ctx {
     uint32_t* totals = nullptr;         // [3][2] device
     unsigned long long* exportSizes = nullptr;   // [16] total + section sizes of the last yk_export_tile_maps
     hipEvent_t evHandoff = nullptr;              // yk_stream_handoff / yk_stream_wait_for
+    hipEvent_t fusedAfter = nullptr;             // yk_order_fused_after: the next fused kernel waits for this event (another handle's)
     uint16_t* defsOut = nullptr;        // [3][T8]
     uint8_t*  nibOut = nullptr;         // [3][T8*32 + 8]
     size_t nibStride = 0;

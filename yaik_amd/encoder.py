@@ -131,6 +131,11 @@ class HipTileEncoder:
     def encode_batch(self, reject_factor: int = 3, mode3bit_only: bool = False):
         _chk(self._h, lib().yk_encode_batch(self._h, reject_factor, int(mode3bit_only)))
 
+    def order_fused_after(self, other: "HipTileEncoder"):
+        """The next encode() of this handle starts its fused kernel after the fused kernel last launched on `other` has finished
+        (device-side wait; see yk_order_fused_after)."""
+        _chk(self._h, lib().yk_order_fused_after(self._h, other._h))
+
     def select_frame(self, f: int):
         _chk(self._h, lib().yk_select_frame(self._h, f))
 
