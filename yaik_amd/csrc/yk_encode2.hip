@@ -8,12 +8,13 @@
 // swizzle block; a LANE owns a whole 4x4 CELL (16 pixels, packed 0x00BBGGRR in 16 VGPRs) for the whole kernel
 // (lane = macroTile*16 + cellY*4 + cellX).  Consequences:
 //   * nothing waits on another wave: no workgroup barriers, ~8.5 KB LDS and 128 VGPRs per wave = 4 waves per SIMD;
-//   * the per-tile work of a gradient pass (corner fetch, Round6/Round6P, row blends) is amortised over 16 pixels per lane;
+//   * the gradient passes run in packed 16-bit arithmetic (two streams per VALU op) on corner values taken from a per-strip lattice
+//     table (Round6 / Round6P precomputed once per lattice point); the per-tile set-up is amortised over 16 pixels per lane;
 //   * a 4x4 tile is one lane, an 8x8 tile four lanes: tile-level reductions are ballots against a lane mask or two shuffles;
 //   * every pass first tests ONE row of every cell; if that already rejects every viable tile of the wave (noise, mild noise)
 //     the other three rows are never evaluated;
-//   * range quantiser: sorted LUTs are searched by quarter (two compares + a 16-byte LDS read + 4 SADs); strips whose live
-//     tiles span <= 16 values go through a 16-bin histogram and per-value tables instead of a per-pixel search;
+//   * range quantiser: index and minDiff of the nearest LUT entry of all six modes come from ONE gather per pixel out of a
+//     per-device table indexed by (rangeDecode, v - BN) — every LUT the reference builds is BN + K[rangeDecode][mode];
 //   * the mode-selection sums are summed in tree order and accepted only when a rigorous rounding margin separates the
 //     modes; ambiguous tiles (rare) are re-summed in the reference's exact sequential order;
 //   * the grid is XCD-aware (runs of 16 blocks per XCD, rotated per group) so halo lines are served by the neighbour's L2.
