@@ -80,6 +80,9 @@ def test_yaik_stream_round_trip_through_decoder_api(built, case):
               "synth1024x3": lambda: synth_planes(1024, n_planes=3)}[case]()
     n, h, w = planes.shape
     got, stream = _run(planes)
+    # (o) the threaded entropy stage (ConvertHotPathBegin / Finish: PaletteCompressor in pass order, ZStd streams on worker threads) writes
+    #     the same file, byte for byte
+    assert got["yaik_file"] == stream and got["yaik_file_parallel"] == got["yaik_file"]
     # (i) the stream is what the oracle's passes give when framed by the same entropy stage: header, [MIPM], GTILs, 1DTL, end
     s = chunks.oracle_streams(planes)
     for k in list(s):

@@ -3,9 +3,15 @@
 // every pixel is processed by the HIP kernels, nothing is computed here.
 #include "EncoderContext.h"
 #include <climits>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "../../include/yaik_hip.h"
 #include "chunks.h"
 #include "palette.h"
+#include "zstd_dl.h"
 
 static const int kPass[7][2] = { {4, 4}, {4, 3}, {3, 4}, {3, 3}, {3, 2}, {2, 3}, {2, 2} };      // EncoderContext.cpp:9057-9093
 
@@ -26,6 +32,7 @@ bool EncoderContext::fail(const char* what) {
 }
 
 void EncoderContext::Release() {
+    ConvertHotPathFinish();
     if (ctx) { yk_destroy(ctx); ctx = nullptr; }
     if (original) { delete original; original = nullptr; }
     bound = alphaDone = encoded = oneDReady = false;
@@ -191,5 +198,111 @@ bool EncoderContext::ConvertHotPath(FILE* f) {
     }
     ok = ok && yaikchunk::writeEndOfFile(f);
     outFile = saved;
+    return ok;
+}
+
+// ---- threaded entropy stage -------------------------------------------------------------------------------------------------------
+namespace {
+// a few worker threads taking jobs from a queue; wait() returns when the queue has drained and every job has finished
+class JobPool {
+public:
+    explicit JobPool(int n) { for (int i = 0; i < (n < 1 ? 1 : n); i++) workers.emplace_back([this] { run(); }); }
+    ~JobPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (auto& t : workers) t.join(); }
+    void push(std::function<void()> job) { { std::lock_guard<std::mutex> g(mu); jobs.push_back(std::move(job)); pending++; } cv.notify_one(); }
+    void wait() { std::unique_lock<std::mutex> g(mu); done.wait(g, [this] { return pending == 0; }); }
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [this] { return stop || !jobs.empty(); }); if (jobs.empty()) return; job = std::move(jobs.front()); jobs.pop_front(); }
+            job();
+            { std::lock_guard<std::mutex> g(mu); if (--pending == 0) done.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers; std::deque<std::function<void()>> jobs; std::mutex mu; std::condition_variable cv, done; int pending = 0; bool stop = false;
+};
+}
+
+struct EncoderContext::EntropyStage {
+    FILE* f = nullptr; int w = 0, h = 0, threads = 1, colorQuad = 250, color1D = 255, range1D = 15;
+    std::vector<u8> bitmap[7], rgb[7], pix, type;
+    std::thread worker; bool ok = true; std::string err;
+    void run() {
+        PaletteResetCodeBook();                         // like ConvertHotPath: the reference converts one image per process
+        std::vector<u8> zBitmap[7], zRgb[7], pal[7], zPix, zType; u32 palSize[7] = {}; bool has[7] = {};
+        std::mutex emu; auto bad = [&](const std::string& e) { std::lock_guard<std::mutex> g(emu); if (ok) { ok = false; err = e; } };
+        {
+            JobPool pool(threads);
+            if (!pix.empty()) {                          // the largest stream first
+                pool.push([&] { std::string e; if (!yaikchunk::compressStream(pix.data(), pix.size(), 18, zPix, e)) bad(e); });
+                pool.push([&] { std::string e; if (!yaikchunk::compressStream(type.data(), type.size(), 18, zType, e)) bad(e); });
+            }
+            for (int i = 0; i < 7; i++) {
+                has[i] = yaikchunk::gradientTileHasChunk(w, h, kPass[i][0], kPass[i][1], bitmap[i].data(), rgb[i].size());
+                if (has[i]) pool.push([&, i] { std::string e; if (!yaikchunk::compressStream(bitmap[i].data(), bitmap[i].size(), 18, zBitmap[i], e)) bad(e); });
+            }
+            for (int i = 0; i < 7; i++) {                // PaletteCompressor in pass order on this thread; each result goes straight to a worker
+                if (!has[i]) continue;
+                pal[i].resize(rgb[i].size() * 3); palSize[i] = (u32)pal[i].size();
+                if (!PaletteCompressor(rgb[i].data(), (int)rgb[i].size(), pal[i].data(), &palSize[i])) { bad("PaletteCompressor overflow"); break; }
+                pal[i].resize(palSize[i]);
+                pool.push([&, i] { std::string e; if (!yaikchunk::compressStream(pal[i].data(), pal[i].size(), 18, zRgb[i], e)) bad(e); });
+            }
+            pool.wait();
+        }
+        std::string e;
+        for (int i = 0; ok && i < 7; i++)
+            if (has[i] && !yaikchunk::emitGradientTile(f, w, h, kPass[i][0], kPass[i][1], bitmap[i].data(), rgb[i].size(), palSize[i], zBitmap[i], zRgb[i], colorQuad, 7, e)) bad(e);
+        if (ok && !pix.empty() && !yaikchunk::emitTile1D(f, pix.size(), type.size(), zPix, zType, color1D, range1D, e)) bad(e);
+        if (ok && !yaikchunk::writeEndOfFile(f)) bad("fwrite");
+    }
+};
+
+bool EncoderContext::ConvertHotPathBegin(FILE* f, int threads) {
+    if (!bound || !f) return fail("ConvertHotPathBegin: SetImageToEncode and an open file first");
+    while ((int)stages.size() >= kMaxStages) retireOldestStage();
+    if (!yaikzstd::available()) return fail(yaikzstd::lastError());      // also: the library is loaded before any worker asks for it
+    FILE* saved = outFile; err.clear();
+    EntropyStage* st = new EntropyStage();
+    st->f = f; st->w = original->GetWidth(); st->h = original->GetHeight(); st->threads = threads;
+    st->colorQuad = colorCompressionQuad; st->color1D = colorCompression1D; st->range1D = rangeCompression1D;
+    bool ok = yaikchunk::writeFileHeader(f, st->w, st->h, original->HasAlpha());
+    outFile = f; fileOutSize = 0;
+    if (ok && original->HasAlpha()) MipPrefilter(true);                    // 'MIPM' is not compressed: written at once
+    outFile = nullptr;                                                     // the passes only collect their raw streams
+    PrepareQuadSmooth();
+    for (int i = 0; ok && i < 7; i++) {
+        FittingQuadSmooth(3, original->GetPlane(0), original->GetPlane(1), original->GetPlane(2), nullptr, false, kPass[i][0], kPass[i][1]);
+        ok = err.empty();
+        st->bitmap[i] = gradBitmap; st->rgb[i] = gradRgb;
+    }
+    if (ok) {
+        st->pix.resize((size_t)st->w * st->h * 3 + 64);
+        u8* wr = st->pix.data();
+        for (int p = 0; p < 3; p++) wr = DynamicTileCompressor(wr, original->GetPlane(p), nullptr, nullptr);
+        st->pix.resize((size_t)(wr - st->pix.data()));
+        st->type = type1d;
+        ok = err.empty();
+    }
+    outFile = saved;
+    if (!ok) { delete st; return false; }
+    stages.push_back(st);
+    st->worker = std::thread([st] { st->run(); });
+    return true;
+}
+
+void EncoderContext::retireOldestStage() {
+    EntropyStage* st = stages.front();
+    stages.erase(stages.begin());
+    st->worker.join();
+    if (!st->ok && stagesOk) { stagesOk = false; stagesErr = st->err; }
+    delete st;
+}
+
+bool EncoderContext::ConvertHotPathFinish() {
+    while (!stages.empty()) retireOldestStage();
+    const bool ok = stagesOk;
+    if (!ok) fail(("ConvertHotPath entropy stage: " + stagesErr).c_str());
+    stagesOk = true; stagesErr.clear();
     return ok;
 }

@@ -45,6 +45,16 @@ public:
     // The chunk sequence of Convert() restricted to this path (:9007-9016, :9057-9093, :9451-9470, :9779-9781): file header,
     // ['MIPM' for RGBA], 7x 'GTIL', '1DTL', terminator — a stream the reference's YAIK_DecodeImage accepts.  Takes no ownership of f.
     bool ConvertHotPath(FILE* f);
+    // The same file, byte for byte, with the entropy stage threaded: PaletteCompressor keeps its pass order on one
+    // thread (its code book carries over from chunk to chunk), the sixteen ZStd streams (7 bitmaps, 7 colour streams, the 1-D pixel and
+    // type streams) are compressed by `threads` workers, the chunks are written in file order.  ConvertHotPathBegin returns as soon as
+    // every raw stream is on the host: the GPU and this object are then free for SetImageToEncode + the passes of the NEXT image while
+    // the previous files are still being compressed (each stage has its own thread and its own PaletteCompressor code book, started
+    // empty like a fresh process; up to kMaxStages images in flight, Begin waits for the oldest beyond that); ConvertHotPathFinish
+    // waits for all of them.  `f` belongs to its stage between Begin and Finish.
+    bool ConvertHotPathBegin(FILE* f, int threads);
+    bool ConvertHotPathFinish();
+    bool ConvertHotPathParallel(FILE* f, int threads) { return ConvertHotPathBegin(f, threads) && ConvertHotPathFinish(); }
 
     // raw streams of the last call of each kind (what the reference compresses and writes, before entropy coding)
     const std::vector<u8>&  LastGradientBitmap() const { return gradBitmap; }             // pFillBitMap (:3775)
@@ -59,6 +69,11 @@ public:
     int                     device;                                                        // HIP device ordinal, set before SetImageToEncode
 
 private:
+    struct EntropyStage;                                // the streams of one image + the thread that compresses and writes them
+    enum { kMaxStages = 8 };
+    std::vector<EntropyStage*> stages;
+    bool stagesOk = true; std::string stagesErr;
+    void retireOldestStage();
     bool ensureEncoded(int rejectFactor, bool mode3, bool wantDst);
     bool fail(const char* what);
     Image* original;

@@ -65,26 +65,39 @@ void gradientExtent(int imgW, int imgH, int sx, int sy, const u8* bitmap, int ou
     }
 }
 
-int writeGradientTile(FILE* f, int imgW, int imgH, int sx, int sy, const u8* bitmap, size_t bitmapBytes, u8* rgb, size_t rgbBytes,
-                      int colorCompression, int planeBit, std::string& err) {
+bool compressStream(const void* src, size_t n, int level, std::vector<u8>& out, std::string& err) { return zcompress(src, n, level, out, err); }
+
+bool gradientTileHasChunk(int imgW, int imgH, int sx, int sy, const u8* bitmap, size_t rgbBytes) {
     int e[4];
     gradientExtent(imgW, imgH, sx, sy, bitmap, e);
-    if (!(e[2] > e[0] && e[3] > e[1] && rgbBytes > 0)) return 0;                          // (:4239)
+    return e[2] > e[0] && e[3] > e[1] && rgbBytes > 0;                                   // (:4239)
+}
+
+bool emitGradientTile(FILE* f, int imgW, int imgH, int sx, int sy, const u8* bitmap, size_t rgbBytes, u32 palSize,
+                      const std::vector<u8>& zBitmap, const std::vector<u8>& zRgb, int colorCompression, int planeBit, std::string& err) {
+    int e[4];
+    gradientExtent(imgW, imgH, sx, sy, bitmap, e);
     HeaderGradientTile h; memset(&h, 0, sizeof h);
     h.bbox.x = (s16)e[0]; h.bbox.y = (s16)e[1]; h.bbox.w = (s16)(e[2] - e[0]);
     h.bbox.h = (s16)(e[3] - e[0]);                                                       // maxY - minX, as the reference writes it (:4258)
     h.format = (u8)(sx | (sy << 3)); h.plane = (u8)planeBit;
+    h.streamBitmapSize = (u32)zBitmap.size(); h.streamRGBSizeZStd = (u32)zRgb.size();
+    h.streamRGBSizeCustomCompressor = palSize; h.streamRGBSizeUncompressed = (u32)rgbBytes;
+    h.colorCompression = (u8)colorCompression;
+    if (!putChunk(f, TAG_GRADTILE, &h, sizeof h, { &zBitmap, &zRgb })) { err = "fwrite"; return false; }
+    return true;
+}
+
+int writeGradientTile(FILE* f, int imgW, int imgH, int sx, int sy, const u8* bitmap, size_t bitmapBytes, u8* rgb, size_t rgbBytes,
+                      int colorCompression, int planeBit, std::string& err) {
+    if (!gradientTileHasChunk(imgW, imgH, sx, sy, bitmap, rgbBytes)) return 0;
     std::vector<u8> zBitmap, zRgb, pal(rgbBytes * 3);
     if (!zcompress(bitmap, bitmapBytes, 18, zBitmap, err)) return -1;                    // CompressStream level 18 (:3697)
     u32 palSize = (u32)pal.size();
     if (!PaletteCompressor(rgb, (int)rgbBytes, pal.data(), &palSize)) { err = "PaletteCompressor overflow"; return -1; }
     pal.resize(palSize);
     if (!zcompress(pal.data(), pal.size(), 18, zRgb, err)) return -1;
-    h.streamBitmapSize = (u32)zBitmap.size(); h.streamRGBSizeZStd = (u32)zRgb.size();
-    h.streamRGBSizeCustomCompressor = palSize; h.streamRGBSizeUncompressed = (u32)rgbBytes;
-    h.colorCompression = (u8)colorCompression;
-    if (!putChunk(f, TAG_GRADTILE, &h, sizeof h, { &zBitmap, &zRgb })) { err = "fwrite"; return -1; }
-    return 1;
+    return emitGradientTile(f, imgW, imgH, sx, sy, bitmap, rgbBytes, palSize, zBitmap, zRgb, colorCompression, planeBit, err) ? 1 : -1;
 }
 
 bool writePlaneTile(FILE* f, const BoundingBox& constraint, const u16* defs, size_t nDefs, const u8* idx, size_t idxBytes,
@@ -99,17 +112,22 @@ bool writePlaneTile(FILE* f, const BoundingBox& constraint, const u16* defs, siz
     return true;
 }
 
-bool writeTile1D(FILE* f, const u8* pix, size_t pixBytes, const u8* type, size_t typeBytes, int compressionColor, int compressionRange,
-                 std::string& err) {
-    if (pixBytes == 0) return true;                                                      // no chunk for an empty stream (:8525)
-    std::vector<u8> zPix, zType;
-    if (!zcompress(pix, pixBytes, 18, zPix, err) || !zcompress(type, typeBytes, 18, zType, err)) return false;
+bool emitTile1D(FILE* f, size_t pixBytes, size_t typeBytes, const std::vector<u8>& zPix, const std::vector<u8>& zType, int compressionColor,
+                int compressionRange, std::string& err) {
     Header1D h; memset(&h, 0, sizeof h);
     h.version = 0; h.compressionColor = (u8)compressionColor; h.compressionRange = (u8)compressionRange;
     h.streamPixelBit = (u32)zPix.size(); h.streamPixelUncmp = (u32)pixBytes;
     h.streamTypeCnt = (u32)zType.size(); h.streamTypeUncmp = (u32)typeBytes;
     if (!putChunk(f, TAG_TILE1D, &h, sizeof h, { &zType, &zPix })) { err = "fwrite"; return false; }      // type first (:8566-8568)
     return true;
+}
+
+bool writeTile1D(FILE* f, const u8* pix, size_t pixBytes, const u8* type, size_t typeBytes, int compressionColor, int compressionRange,
+                 std::string& err) {
+    if (pixBytes == 0) return true;                                                      // no chunk for an empty stream (:8525)
+    std::vector<u8> zPix, zType;
+    if (!zcompress(pix, pixBytes, 18, zPix, err) || !zcompress(type, typeBytes, 18, zType, err)) return false;
+    return emitTile1D(f, pixBytes, typeBytes, zPix, zType, compressionColor, compressionRange, err);
 }
 
 }  // namespace yaikchunk

@@ -21,6 +21,15 @@ bool writePlaneTile(FILE* f, const BoundingBox& constraint, const u16* defs, siz
 // '1DTL' (GenerateDynamicTileChunk, :8524-8576): type stream first, then the pixel stream
 bool writeTile1D(FILE* f, const u8* pix, size_t pixBytes, const u8* type, size_t typeBytes, int compressionColor,
                  int compressionRange, std::string& err);
+// The two compressed chunk kinds in split form, for a threaded entropy stage (EncoderContext::ConvertHotPathBegin): the streams are
+// compressed wherever (compressStream = CompressStream, :3692-3708: plain ZSTD_compress at the given level), the chunks are emitted
+// in file order.  writeGradientTile / writeTile1D are these two steps back to back.
+bool compressStream(const void* src, size_t n, int level, std::vector<u8>& out, std::string& err);
+bool gradientTileHasChunk(int imgW, int imgH, int tileShiftX, int tileShiftY, const u8* bitmap, size_t rgbBytes);
+bool emitGradientTile(FILE* f, int imgW, int imgH, int tileShiftX, int tileShiftY, const u8* bitmap, size_t rgbBytes, u32 paletteBytes,
+                      const std::vector<u8>& zBitmap, const std::vector<u8>& zRgb, int colorCompression, int planeBit, std::string& err);
+bool emitTile1D(FILE* f, size_t pixBytes, size_t typeBytes, const std::vector<u8>& zPix, const std::vector<u8>& zType,
+                int compressionColor, int compressionRange, std::string& err);
 // extent of the set bits of a swizzled gradient bitmap in pixels: {minX, minY, maxX, maxY} (:3798-3799, :4039-4042)
 void gradientExtent(int imgW, int imgH, int tileShiftX, int tileShiftY, const u8* bitmap, int out[4]);
 }

@@ -86,6 +86,18 @@ int main(int argc, char** argv) {
         fseek(yf, 0, SEEK_SET);
         if (fread(stream.data(), 1, (size_t)n, yf) != (size_t)n) return 2;
         fclose(yf);
+        blob("yaik_file", stream.data(), (size_t)n);
+        {   // the same image through the threaded entropy stage: the file must be identical, byte for byte
+            FILE* pf = tmpfile(); if (!pf) return 2;
+            if (!ctx->ConvertHotPathParallel(pf, 4)) { fprintf(stderr, "ConvertHotPathParallel: %s\n", ctx->LastError()); return 4; }
+            fflush(pf);
+            const long pn = ftell(pf);
+            std::vector<u8> pbytes((size_t)pn);
+            fseek(pf, 0, SEEK_SET);
+            if (pn && fread(pbytes.data(), 1, pbytes.size(), pf) != pbytes.size()) return 2;
+            fclose(pf);
+            blob("yaik_file_parallel", pbytes.data(), pbytes.size());
+        }
         YAIK_LIB lib = YAIK_Init(1, nullptr);
         if (!lib) { fprintf(stderr, "YAIK_Init failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
         YAIK_SDecodedImage di;

@@ -5,9 +5,12 @@
 
 namespace {
 struct Code { int ref, r, g, b; };
-std::vector<Code> gCodes(100000, Code{0, 0, 0, 0});     // the reference's table has 100000 rows (:3216) and overflows beyond; this one grows
-int gCodeCount = 0;
-std::unordered_map<u32, int> gRowOf;                    // delta -> row, this call only (the reference scans linearly: same row found)
+// One table per THREAD: within a thread it behaves like the reference's process-global table (rows carry over from call to call);
+// entropy stages of different images, each on its own thread and starting from PaletteResetCodeBook like a fresh process, do not
+// see each other (EncoderContext::ConvertHotPathBegin).
+thread_local std::vector<Code> gCodes(100000, Code{0, 0, 0, 0});     // the reference's table has 100000 rows (:3216) and overflows beyond; this one grows
+thread_local int gCodeCount = 0;
+thread_local std::unordered_map<u32, int> gRowOf;       // delta -> row, this call only (the reference scans linearly: same row found)
 
 inline u32 deltaKey(int dr, int dg, int db) { return (u32)(dr + 256) | ((u32)(dg + 256) << 10) | ((u32)(db + 256) << 20); }
 void registerCode(int dr, int dg, int db) {

@@ -3,7 +3,7 @@
 //   PaletteDecompressor  decoder/YAIK_GenericFunctions.cpp:139-241 (+ PaletteFullRangeRemapping :128-137)
 // Same signatures and return conventions as the reference.  The code table is process-global like the reference's
 // CodeRGB/CodeCount (:3216-3217): FindCodeBook scans rows 0..63 whether or not the current call filled them, so rows left
-// over from an earlier call take part in the match — kept, because the emitted bytes depend on it.
+// over from an earlier call take part in the match — kept, because the emitted bytes depend on it.  (Global per thread: see palette.cpp.)
 #pragma once
 #include "framework.h"
 
