@@ -42,7 +42,12 @@
   X(37, "v_pk_fma_f32 %0, %0, %1, %1", 2) \
   X(38, "v_pk_mul_f32 %0, %0, %1", 2) \
   X(39, "v_pk_add_f32 %0, %0, %1", 2) \
-  X(40, "v_pk_mov_b32 %0, %0, %1", 2)
+  X(40, "v_pk_mov_b32 %0, %0, %1", 2) \
+  X(41, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]", 1) \
+  X(42, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]", 1) \
+  X(43, "v_cvt_f32_ubyte2 %0, %0", 0) \
+  X(44, "v_cvt_f32_f16 %0, %0", 1) \
+  X(45, "v_dot2c_f32_f16 %0, %1, %2", 1)
 template <int KIND>
 __global__ void k(uint32_t* out, uint32_t seed, int iters) {
     uint32_t a[8]; float f[8]; uint64_t d[8];
