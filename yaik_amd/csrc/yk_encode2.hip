@@ -30,6 +30,15 @@ __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
 // |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
 __device__ __forceinline__ uint32_t y2_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Values of the other lanes of an 8x8 tile {l, l^1, l^4, l^5} through DPP instead of the LDS crossbar (ds_bpermute): lane^1 is a
+// quad permutation; lane^4 is row_shl:4 for the quads with bit 2 clear and row_shr:4 for the others (bank masks select them).
+__device__ __forceinline__ int y2_lane_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }          // quad_perm:[1,0,3,2]
+__device__ __forceinline__ int y2_lane_xor4(int v) {
+    const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);                                                       // row_shl:4, banks 0 and 2
+    return __builtin_amdgcn_update_dpp(up, v, 0x114, 0xF, 0xA, false);                                                              // row_shr:4, banks 1 and 3
+}
+__device__ __forceinline__ float y2_lane_xor1(float v) { return __int_as_float(y2_lane_xor1(__float_as_int(v))); }
+__device__ __forceinline__ float y2_lane_xor4(float v) { return __int_as_float(y2_lane_xor4(__float_as_int(v))); }
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
@@ -508,8 +517,8 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 #pragma unroll
                 for (int k = 0; k < 16; k++) { const int v = y2_byte(pw[k], p); mn = min(mn, v); mx = max(mx, v); }
             }
-            mn = min(mn, __shfl_xor(mn, 1)); mx = max(mx, __shfl_xor(mx, 1));
-            mn = min(mn, __shfl_xor(mn, 4)); mx = max(mx, __shfl_xor(mx, 4));
+            mn = min(mn, y2_lane_xor1(mn)); mx = max(mx, y2_lane_xor1(mx));
+            mn = min(mn, y2_lane_xor4(mn)); mx = max(mx, y2_lane_xor4(mx));
             if (mn == 99999999) { mn = 0; mx = 0; }
             // DynamicTile::buildTable (:625-699)
             const int min_ = min(mn, 224);
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             for (int m = 0; m < 6; m++) {
                 if (m >= P.startMode) {
                     float t = sm[m];
-                    t = __fadd_rn(t, __shfl_xor(t, 1)); t = __fadd_rn(t, __shfl_xor(t, 4));
+                    t = __fadd_rn(t, y2_lane_xor1(t)); t = __fadd_rn(t, y2_lane_xor4(t));
                     bool take;
                     if (bestMode < 0) take = true;
                     else if (__fmul_rn(t, 1.00002f) < bestT) take = true;                        // surely smaller
