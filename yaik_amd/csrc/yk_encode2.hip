@@ -121,8 +121,9 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
             const int i = (r & 1) ? 3 - ii : ii;                         // serpentine: odd rows right to left
             const uint32_t p = pwb[r * 4 + i];
             // 256 * (cur - 128) of channel c in both halves; stream 3: channel 0 | channel 1
-            const y2s2 cc[4] = { y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x000C000Cu))), y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C010Cu))),
-                                 y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu))), y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))) };
+            // two byte permutations per pixel; the broadcasts of one half are operand selects (op_sel) of the packed subtract
+            const y2s2 c01 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))), c22 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu)));
+            const y2s2 cc[4] = { __builtin_shufflevector(c01, c01, 0, 0), __builtin_shufflevector(c01, c01, 1, 1), c22, c01 };
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(S[t]), cc[t == 4 ? 2 : t]);
