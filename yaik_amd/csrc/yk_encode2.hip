@@ -99,8 +99,6 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     const int loO = -256 * rf, hiO = 256 * rf + 255;
     const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
     y2s2 mn[5], mx[5];
-#pragma unroll
-    for (int t = 0; t < 5; t++) { mn[t] = y2_splats(32767); mx[t] = y2_splats(-32768); }
     unsigned long long bO[3], bR[3];
     auto variants = [&]() {                                              // lanes failing each of the six variants, so far
         const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]);   // (raw | Round6) over the channels
@@ -127,7 +125,8 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(S[t]), cc[t == 4 ? 2 : t]);
-                mn[t] = __builtin_elementwise_min(mn[t], D); mx[t] = __builtin_elementwise_max(mx[t], D);
+                if (r == 0 && ii == 0) { mn[t] = D; mx[t] = D; }             // the first pixel starts the running extremes
+                else { mn[t] = __builtin_elementwise_min(mn[t], D); mx[t] = __builtin_elementwise_max(mx[t], D); }
                 if (ii < 3) S[t] = (r & 1) ? S[t] + st[t] : S[t] - st[t];
             }
         }
