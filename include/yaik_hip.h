@@ -115,7 +115,8 @@ int yk_select_frame(yk_ctx* c, int frame);
  * With two handles (two streams) in flight the HBM-bound alpha / compaction kernels of one frame run under the fused kernel of
  * the other.  Two fused kernels sharing the chip only slow each other down, so a caller that alternates handles can order them:
  * the NEXT yk_encode_tiles of c launches its fused kernel after the fused kernel most recently launched on `other` has finished
- * (a stream-wait on an event, no host synchronisation; the alpha stage and the compaction of c are not held back).  Same device. */
+ * (a stream-wait on an event, no host synchronisation; the alpha stage and the compaction of c are not held back).  Same device;
+ * `other` must stay alive until that yk_encode_tiles of c has been issued (the event belongs to it). */
 int yk_order_fused_after(yk_ctx* c, const yk_ctx* other);
 
 /* gradient results (valid after yk_encode_tiles) -------------------------------------------------
