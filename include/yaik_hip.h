@@ -190,9 +190,15 @@ int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int tileBBoxW, int tileBBoxH,
 int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, size_t capEach);
 const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
 /* internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191): de-tile into interleaved rows at outputImageStride.
- * hostAlpha == NULL -> RGB, 3 B/pixel, byte-identical to the reference.  With a linear 8-bit alpha plane (strideA bytes per
- * row) the output is RGBA 4 B/pixel as include/YAIK.h documents; the reference's own RGBA branch is broken (:53-60). */
+ * Only the pixel bytes of a row are written; the rest of each outputImageStride-sized row is left untouched, like the reference
+ * (include/YAIK.h:190: the stride places the image inside a larger user buffer).
+ * hostAlpha == NULL -> RGB, 3 B/pixel, byte-identical to the reference (pinned by the compiled reference: tests/golden, blob dec_rgb_out).
+ * With a linear 8-bit alpha plane (strideA bytes per row) yk_decode_output writes RGBA 4 B/pixel as include/YAIK.h documents.
+ * The reference's own RGBA branch does something else (:45-62: the alpha store never advances dst and the alpha row cursors are
+ * not moved per tile row): rows of w RGB triples + one alpha byte.  yk_decode_output_reference_rgba reproduces exactly that
+ * (blob dec_rgba_out) for callers that need byte identity with the reference's output rather than a usable RGBA image. */
 int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA);
+int yk_decode_output_reference_rgba(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA);
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------

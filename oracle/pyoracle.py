@@ -59,6 +59,7 @@ def _load() -> C.CDLL:
     lib.yko_dec_split_masks.argtypes = [vp]
     lib.yko_dec_1d.argtypes = [vp, C.c_int, vp, ip, vp, ip, C.c_int]
     lib.yko_dec_mask.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.yko_image_builder.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
     for name in ("yko_dec_planes", "yko_dec_tile4x4", "yko_dec_map_rgb", "yko_dec_map_rgb_mask"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, ip]
@@ -224,6 +225,27 @@ def palette_decompress(pal: np.ndarray, out_size: int, color_compression: int = 
     ok = lib().yko_palette_decompress(buf.ctypes.data, int(pal.size), out.ctypes.data, out_size, color_compression)
     if not ok:
         raise RuntimeError("PaletteDecompressor rejected the stream")
+    return out
+
+
+def dec_mask(bits: np.ndarray, bw: int, bh: int) -> np.ndarray:
+    """Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154): 1 bit per 16x16 tile of the bw x bh tile box -> swizzled 1 bit / pixel."""
+    src = np.concatenate([np.ascontiguousarray(bits, dtype=np.uint8), np.zeros(8, np.uint8)])
+    out = np.zeros((bw * bh * 256) // 8, dtype=np.uint8)
+    lib().yko_dec_mask(src.ctypes.data, bw, bh, out.ctypes.data)
+    return out
+
+
+def image_builder(planes_tiled: np.ndarray, w: int, h: int, stride: int, alpha: np.ndarray = None, fill: int = 0xA5) -> np.ndarray:
+    """internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191) -> [h, stride] bytes; bytes the reference does not
+    write keep `fill`.  alpha (h x w u8, linear) selects the reference's RGBA branch, reproduced with its defects."""
+    pl = np.ascontiguousarray(planes_tiled, dtype=np.uint8).reshape(3, -1)
+    out = np.full((h, stride), fill, dtype=np.uint8)
+    a = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.uint8)
+    rc = lib().yko_image_builder(pl.ctypes.data, pl.shape[1], w, h, None if a is None else a.ctypes.data, 0 if a is None else a.shape[1],
+                                 out.ctypes.data, stride)
+    if rc != 0:
+        raise ValueError("image_builder: width / height must be multiples of 8")
     return out
 
 

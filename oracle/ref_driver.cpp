@@ -11,6 +11,8 @@
 //   EncoderContext::DynamicTileCompressor                         :8398
 //   DecompressGradient16x16..4x4          decoder/YAIK_Gradient.cpp:28..1208
 //   Decompress1D                          decoder/YAIK_3DTile.cpp:24
+//   Decompress1BitTiled                   decoder/YAIK_Mipmap.cpp:23   (on the 'MIPM' chunk MipPrefilter itself wrote)
+//   internal_imageBuilderFunc             decoder/YAIK_DefaultCallback.cpp:24 (RGB at a padded outputImageStride; RGBA as the reference does it)
 //
 // The reference frees its raw streams before returning, so they are captured where they cross a
 // translation-unit boundary, with the GNU linker's --wrap of ZSTD_compress (raw tile bitmaps, tile
@@ -53,6 +55,14 @@ extern "C" size_t __wrap_ZSTD_compress(void* dst, size_t dstCap, const void* src
     static const bool keep = getenv("YK_REF_KEEP_LEVEL") != NULL;
     return __real_ZSTD_compress(dst, dstCap, src, srcSize, keep ? level : 1);
 }
+
+// ---- plumbing decoder/YAIK_API.cpp (not buildable here, see Makefile) would have supplied to YAIK_Mipmap.cpp / YAIK_Alpha.cpp
+// (declared in decoder/YAIK_functions.h:22-24; definitions YAIK_API.cpp:27-57).  The loops under test stay unmodified.
+static int gLastError = 0, gErrorCalls = 0;
+void SetErrorCode(YAIK_ERROR_CODE error) { gLastError = (int)error; gErrorCalls++; }      // recorder, never aborts
+u8*  AllocateMem(YAIK_SMemAlloc*, size_t size) { return (u8*)calloc(size ? size : 1, 1); }
+void FreeMem(YAIK_SMemAlloc*, void* ptr) { free(ptr); }
+void internal_imageBuilderFunc(struct YAIK_SDecodedImage* userInfo, struct YAIK_SCustomDataSource* sourceImageInternal);   // YAIK_DefaultCallback.cpp:24
 
 #include <time.h>
 static double nowSec() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -117,6 +127,7 @@ int main(int argc, char** argv) {
     blob("meta", meta, sizeof meta);
 
     double stage[3] = { 0, 0, 0 };                   // seconds: MipPrefilter, 7x FittingQuadSmooth, 3x DynamicTileEncode (4-bpp)
+    std::vector<u8> mipChunk;                        // the 'MIPM' chunk as MipPrefilter wrote it (empty: none)
     // ---- a9 alpha tile-reject ----
     if (np == 4) {
         long before = ftell(ctx->outFile);
@@ -130,6 +141,7 @@ int main(int argc, char** argv) {
         if (!chunk.empty() && fread(chunk.data(), 1, chunk.size(), ctx->outFile) != chunk.size()) return 2;
         fseek(ctx->outFile, after, SEEK_SET);
         blob("mip_chunk", chunk.data(), chunk.size());
+        mipChunk = chunk;
         int b[6] = { ctx->boundX0, ctx->boundY0, ctx->boundX1, ctx->boundY1, ctx->mipMapTileSize, ctx->remainingPixels };
         blob("mip_bounds", b, sizeof b);
         blobPlane8("mip_mask", ctx->mipmapMask);
@@ -278,6 +290,51 @@ int main(int argc, char** argv) {
     int consumed[2] = { (int)(tp - typPad.data()), (int)(pp - pixPad.data()) };
     blob("dec_1d_consumed", consumed, sizeof consumed);
     blob("dec_planes_full", planes.data(), planes.size());
+
+    // ---- a18 Decompress1BitTiled on the reference's own 'MIPM' payload (chunk reader: decoder/YAIK_API.cpp:732-749) ----
+    if (mipChunk.size() > sizeof(HeaderBase) + sizeof(MipmapHeader)) {
+        MipmapHeader mh; memcpy(&mh, mipChunk.data() + sizeof(HeaderBase), sizeof mh);
+        std::vector<u8> payload(mipChunk.begin() + sizeof(HeaderBase) + sizeof(MipmapHeader), mipChunk.end());
+        size_t payloadLen = payload.size(); payload.resize(payloadLen + 64, 0);
+        gLastError = 0; gErrorCalls = 0;
+        inst.mipMapMask = NULL;
+        bool ok = Decompress1BitTiled(&inst, &mh, payload.data(), (u32)payloadLen);
+        int info[8] = { mh.bbox.x, mh.bbox.y, mh.bbox.w, mh.bbox.h, (int)mh.mipmapLevel, ok ? 1 : 0, gLastError, gErrorCalls };
+        blob("dec_mask_info", info, sizeof info);
+        int mb[4] = { inst.maskBBox.x, inst.maskBBox.y, inst.maskBBox.w, inst.maskBBox.h };
+        blob("dec_mask_bbox", mb, sizeof mb);
+        if (ok && inst.mipMapMask) blob("dec_mask", inst.mipMapMask, ((size_t)inst.maskBBox.w * inst.maskBBox.h) >> 3);
+        free(inst.mipMapMask); inst.mipMapMask = NULL;
+    }
+
+    // ---- a20 internal_imageBuilderFunc on the fully decoded tiled planes: RGB rows at a padded outputImageStride, and (4-plane
+    // inputs) the RGBA branch exactly as the reference executes it, alpha = the source alpha plane as a linear 8-bit buffer ----
+    {
+        YAIK_SCustomDataSource src; memset(&src, 0, sizeof src);
+        src.planeR = inst.planeR; src.planeG = inst.planeG; src.planeB = inst.planeB; src.planeA = NULL;
+        src.strideR = src.strideG = src.strideB = inst.tileWidth * 64;
+        YAIK_SDecodedImage user; memset(&user, 0, sizeof user);
+        user.width = (u16)w; user.height = (u16)h; user.hasAlpha = false;
+        int stride = w * 3 + 13;
+        std::vector<u8> out((size_t)stride * h + 64, 0xA5);
+        user.outputImage = out.data(); user.outputImageStride = stride;
+        internal_imageBuilderFunc(&user, &src);
+        int si[2] = { stride, 3 };
+        blob("dec_rgb_out_info", si, sizeof si);
+        blob("dec_rgb_out", out.data(), (size_t)stride * h);
+        if (np == 4) {
+            std::vector<u8> alpha((size_t)w * h);
+            for (size_t i = 0; i < alpha.size(); i++) alpha[i] = (u8)img->GetPlane(3)->GetPixels()[i];
+            src.planeA = alpha.data(); src.strideA = w; user.hasAlpha = true;
+            int strideA = w * 4 + 20;
+            std::vector<u8> outA((size_t)strideA * h + 64, 0xA5);
+            user.outputImage = outA.data(); user.outputImageStride = strideA;
+            internal_imageBuilderFunc(&user, &src);
+            int sa[2] = { strideA, 4 };
+            blob("dec_rgba_out_info", sa, sizeof sa);
+            blob("dec_rgba_out", outA.data(), (size_t)strideA * h);
+        }
+    }
 
     fclose(gOut);
     fclose(ctx->outFile);

@@ -757,9 +757,10 @@ int yko_dec_1d(yko_dec* d, int plane, const uint8_t* type, int* typePos, const u
     return tiles;
 }
 
-/* a18: Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154), tile width 16: each source bit becomes a 16x16
- * block of ones in a mask stored as rows of u64 pairs: two u64 (=16 px x 8 rows?) -- the reference writes, per
- * tile, v,v to row-group A and v,v to row-group B where a "row" is tileWidth*2 u64 (:119-136). */
+/* a18: Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154), mipmapLevel 4 (the only implemented one, :139-147): source bit
+ * `pos` (tile-bbox row-major, LSB first, :124) becomes a 16x16 block of ones in a mask stored as u64 words, 16 pixels x 4 rows
+ * per word pair: per tile the reference writes v,v into row group A and v,v into row group B = A + 2*tileWidth words, then both
+ * cursors skip the other group (:119-136).  Pinned against the compiled reference (blob dec_mask of oracle/ref_driver.cpp). */
 int yko_dec_mask(const uint8_t* bits, int bw, int bh, uint8_t* out) {
     uint64_t* tile = (uint64_t*)out;
     uint64_t* A = tile; uint64_t* B = A + ((size_t)bw << 1);
@@ -773,6 +774,37 @@ int yko_dec_mask(const uint8_t* bits, int bw, int bh, uint8_t* out) {
         A += (size_t)bw << 1; B += (size_t)bw << 1;
     }
     return (bw * bh * 256) >> 3;
+}
+
+/* a20: internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191) for widths / heights that are multiples of 8 (the
+ * clipped right / bottom branches :85-190 are not restated: Image::LoadPNG only admits multiples of 8, Image.cpp:206).
+ * planes = R|G|B 8x8-tiled u8 (planeSize bytes each); out rows are `stride` bytes apart, bytes the loop does not write are left.
+ *   alpha == NULL: 3 bytes per pixel (:64-79).
+ *   alpha != NULL: the reference's RGBA branch AS IT IS (:45-62): `*dst = *pAlpha++` stores the alpha byte WITHOUT advancing dst,
+ *   so the next pixel's red overwrites it -> rows of RGB triples followed by ONE alpha byte at offset 3*w; and the alpha row
+ *   cursors pAL[n] (:36-39) are never moved to the next tile row (only dst_pL is, :128-130), so tile row t reads alpha rows
+ *   t .. t+7.  Reproduced, not fixed: the product documents its own RGBA layout separately (include/yaik_hip.h). */
+int yko_image_builder(const uint8_t* planes, int planeSize, int w, int h, const uint8_t* alpha, int strideA, uint8_t* out, int stride) {
+    if ((w & 7) || (h & 7)) return -1;
+    const uint8_t* pR = planes; const uint8_t* pG = planes + planeSize; const uint8_t* pB = planes + 2 * (size_t)planeSize;
+    uint8_t* rowL[8]; const uint8_t* pAL[8];
+    for (int n = 0; n < 8; n++) { rowL[n] = out + (size_t)stride * n; pAL[n] = alpha ? alpha + (size_t)strideA * n : NULL; }
+    for (int ty = 0; ty < h; ty += 8) {
+        uint8_t* dst[8];
+        for (int n = 0; n < 8; n++) dst[n] = rowL[n];
+        for (int tx = 0; tx < (w >> 3); tx++) {
+            for (int n = 0; n < 8; n++) {
+                uint8_t* d = dst[n];
+                for (int k = 0; k < 8; k++) {
+                    *d++ = *pR++; *d++ = *pG++; *d++ = *pB++;
+                    if (alpha) *d = *pAL[n]++;
+                }
+                dst[n] = d;
+            }
+        }
+        for (int n = 0; n < 8; n++) rowL[n] += (size_t)stride << 3;
+    }
+    return 0;
 }
 
 const uint8_t* yko_dec_planes(const yko_dec* d, int* planeSize) { *planeSize = d->planeSize; return d->planes; }

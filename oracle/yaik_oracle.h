@@ -8,9 +8,9 @@
  * reference sources compiled by oracle/Makefile (oracle/_ref/ref_driver) in
  * tests/test_oracle_vs_reference.py, and against the committed vectors in tests/golden/ that the
  * same binary produced (generator: tests/golden/make_golden.py).  The reference ships no tests or
- * fixtures of its own.  Exception: yko_dec_mask (Decompress1BitTiled) — its TU needs
- * decoder/YAIK_API.cpp, which is unbuildable here; it is restated from the source text and pinned
- * by hand-derived vectors only.
+ * fixtures of its own.  Since round 2 this includes yko_dec_mask (Decompress1BitTiled,
+ * decoder/YAIK_Mipmap.cpp) and yko_image_builder (internal_imageBuilderFunc, decoder/YAIK_DefaultCallback.cpp):
+ * both translation units are compiled into ref_driver (blobs dec_mask, dec_rgb_out, dec_rgba_out).
  */
 #ifndef YAIK_ORACLE_H
 #define YAIK_ORACLE_H
@@ -94,6 +94,9 @@ void yko_dec_split_masks(yko_dec* d);
 int yko_dec_1d(yko_dec* d, int plane, const uint8_t* type, int* typePos, const uint8_t* pix, int* pixPos, int compressionRange);
 /* Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154), mipmapLevel 4 only. out = (bw*bh*256)/8 bytes swizzled mask. */
 int yko_dec_mask(const uint8_t* bits, int tileBBoxW, int tileBBoxH, uint8_t* out);
+/* internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191), w/h multiples of 8; alpha nullable (then 3 B/pixel).
+ * With alpha the reference's RGBA branch is reproduced as it executes (RGB triples + one alpha byte per row, see the .c). */
+int yko_image_builder(const uint8_t* planes, int planeSize, int w, int h, const uint8_t* alpha, int strideA, uint8_t* out, int stride);
 
 const uint8_t* yko_dec_planes(const yko_dec* d, int* planeSize);     /* R|G|B, 8x8-tiled u8 */
 const uint8_t* yko_dec_tile4x4(const yko_dec* d, int* sizePerPlane);

@@ -2,10 +2,12 @@
 so that golden fixtures (tests/golden/*.npz, hashes.json) and live reference runs can be compared name by name."""
 import numpy as np
 
-from oracle.pyoracle import (PASSES, OracleDecoder, OracleEncoder, palette_decompress)
+from oracle.pyoracle import (PASSES, OracleDecoder, OracleEncoder, dec_mask, image_builder, palette_decompress)
 
-# blobs whose bytes depend on uninitialised reference memory or that the fixtures do not keep
-SKIP = {"meta", "mip_chunk", "dec_mapRGB", "chunks_file", "stage_seconds"}      # chunks_file: see tests/test_host_chunks.py
+# blobs whose bytes depend on uninitialised reference memory or that the fixtures do not keep; dec_mask_info carries the error
+# code CheckInBound2D's missing `return true` (decoder/YAIK_Alpha.cpp:12-23, UB) happens to produce
+SKIP = {"meta", "mip_chunk", "dec_mapRGB", "chunks_file", "stage_seconds", "dec_mask_info"}      # chunks_file: see tests/test_host_chunks.py
+RGB_OUT_PAD, RGBA_OUT_PAD = 13, 20                     # row padding ref_driver.cpp gives the two outputImageStride values
 
 
 def oracle_blobs(planes: np.ndarray) -> dict:
@@ -13,12 +15,12 @@ def oracle_blobs(planes: np.ndarray) -> dict:
     out = {}
     enc = OracleEncoder(planes)
     if n == 4:
-        m = enc.mip_prefilter()
-        out["mip_bounds"] = np.array(list(m["bounds"]) + [16, m["remaining"]], dtype=np.int32).tobytes()
+        mip = enc.mip_prefilter()
+        out["mip_bounds"] = np.array(list(mip["bounds"]) + [16, mip["remaining"]], dtype=np.int32).tobytes()
         out["mip_mask"] = enc.state("mipmapMask").tobytes()
-        out["_mip_bitmap"] = m["bitmap"].tobytes()
-        out["_mip_tile_bbox"] = m["tile_bbox"].astype(np.int16).tobytes()
-        out["_mip_has_chunk"] = bytes([int(m["has_chunk"])])
+        out["_mip_bitmap"] = mip["bitmap"].tobytes()
+        out["_mip_tile_bbox"] = mip["tile_bbox"].astype(np.int16).tobytes()
+        out["_mip_has_chunk"] = bytes([int(mip["has_chunk"])])
     counts, streams = [], []
     for i, (sx, sy) in enumerate(PASSES):
         cnt, bm, rgb = enc.fitting_quad_smooth(sx, sy)
@@ -67,6 +69,17 @@ def oracle_blobs(planes: np.ndarray) -> dict:
         tp, pp = dec.decode_1d(typ, pix)
         out["dec_1d_consumed"] = np.array([tp, pp], dtype=np.int32).tobytes()
         out["dec_planes_full"] = dec.planes().tobytes()
+        # a20 default image builder on the decoded planes (RGB at a padded stride; RGBA as the reference executes it)
+        out["dec_rgb_out_info"] = np.array([w * 3 + RGB_OUT_PAD, 3], dtype=np.int32).tobytes()
+        out["dec_rgb_out"] = image_builder(dec.planes(), w, h, w * 3 + RGB_OUT_PAD).tobytes()
+        if n == 4:
+            out["dec_rgba_out_info"] = np.array([w * 4 + RGBA_OUT_PAD, 4], dtype=np.int32).tobytes()
+            out["dec_rgba_out"] = image_builder(dec.planes(), w, h, w * 4 + RGBA_OUT_PAD, alpha=planes[3].astype(np.uint8)).tobytes()
+        # a18 reject-mask expansion of the 'MIPM' payload
+        if n == 4 and mip["has_chunk"]:
+            bx, by, bw, bh = (int(v) for v in mip["tile_bbox"])
+            out["dec_mask_bbox"] = np.array([bx * 16, by * 16, bw * 16, bh * 16], dtype=np.int32).tobytes()
+            out["dec_mask"] = dec_mask(mip["bitmap"], bw, bh).tobytes()
     return out
 
 

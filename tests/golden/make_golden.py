@@ -19,7 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle.refrun import have_ref, run_reference  # noqa: E402
-from tests.images import edge_image, synth_planes  # noqa: E402
+from tests.images import edge_image, lineart_image, natural_photo, synth_planes  # noqa: E402
+
+PHOTO_SRC = "/opt/conda/lib/python3.9/site-packages/skimage/data/astronaut.png"       # present in the build image; never read by tests
+PHOTO_INPUT = os.path.join(HERE, "photo_astronaut256_input.npz")
 
 FULL = {   # name -> planes factory; every reference blob is stored
     "synth64_rgb": lambda: synth_planes(64, n_planes=3),
@@ -32,12 +35,24 @@ HASHED = {  # name -> planes factory; SHA-256 per blob
     "synth512_rgba": lambda: synth_planes(512, n_planes=4),
     "synth1024_rgba": lambda: synth_planes(1024, n_planes=4),
     "mixed208x144_rgb": lambda: edge_image(208, 144, "mixed", 3),
+    "lineart1024_rgba": lambda: lineart_image(1024, 4),          # procedurally drawn flat-colour illustration, anti-aliased edges
+    "photo_astronaut256_rgb": natural_photo,                     # natural photograph (committed crop, see write_photo_input)
 }
 # blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
 DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_")
 
 
+def write_photo_input():
+    """(Re)creates the committed input crop from the PNG when the build image has it; otherwise the committed file is used as is."""
+    if not os.path.exists(PHOTO_SRC):
+        return
+    from PIL import Image
+    im = np.asarray(Image.open(PHOTO_SRC).convert("RGB"))
+    np.savez_compressed(PHOTO_INPUT, rgb=np.ascontiguousarray(im[32:288, 96:352]))
+
+
 def main():
+    write_photo_input()
     if not have_ref():
         print("oracle/_ref/ref_driver is missing: run `make -C oracle` on a machine that has /root/reference", file=sys.stderr)
         return 1

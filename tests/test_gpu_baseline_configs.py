@@ -26,6 +26,14 @@ def test_c2_4096_rgba_full_encode_4bpp_bit_exact(hip, oracle_built):
     assert not bad, bad
 
 
+def test_headline_8192_rgba_4bpp_bit_exact(hip, oracle_built):
+    """BASELINE.json's metric shape itself (8192x8192 RGBA, 4-bpp modes): alpha reject bitmap / bounds, the seven tile bitmaps, corner
+    streams, coverage, tile definitions and nibble streams bit-exact against the oracle (the frame bench.py times)."""
+    from yaik_amd.synth import synth_planes
+    bad = compare_encode(synth_planes(8192, n_planes=4), hip, False, want_dst=False, check_corners=True)
+    assert not bad, bad
+
+
 def test_c3_8192_rgb_3bpp_bit_exact(hip, oracle_built):
     """configs[2]: 8192x8192 RGB, gradient fit all sizes + 8x8 3-bpp range quantiser"""
     from yaik_amd.synth import synth_planes

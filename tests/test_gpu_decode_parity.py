@@ -64,13 +64,18 @@ def test_decode_matches_oracle(dec, oracle_built, kind, w, h):
     mse = float(np.mean(err ** 2))
     psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
     assert psnr > 30.0, psnr
-    # a20 default image builder: interleaved RGB rows at outputImageStride == numpy de-tile of the planes
-    img = dec.image(stride=w * 3 + 8)
+    # a20 default image builder: interleaved RGB rows at outputImageStride == the oracle's restatement of internal_imageBuilderFunc
+    # (pinned against the compiled reference), row padding untouched
+    from oracle.pyoracle import image_builder
+    img = dec.image(stride=w * 3 + 13, fill=0xA5)
+    assert np.array_equal(img, image_builder(gp, w, h, w * 3 + 13))
     want = np.stack([detile(gp[c], w, h) for c in range(3)], axis=-1).reshape(h, w * 3)
-    assert np.array_equal(img[:, : w * 3], want) and not img[:, w * 3:].any()
+    assert np.array_equal(img[:, : w * 3], want) and (img[:, w * 3:] == 0xA5).all()
     alpha = (np.arange(h * w, dtype=np.int64).reshape(h, w) % 251).astype(np.uint8)
-    rgba = dec.image(alpha=alpha).reshape(h, w, 4)
+    rgba = dec.image(alpha=alpha).reshape(h, w, 4)                      # the documented RGBA layout (include/YAIK.h)
     assert np.array_equal(rgba[..., :3], want.reshape(h, w, 3)) and np.array_equal(rgba[..., 3], alpha)
+    ref_rgba = dec.image(alpha=alpha, stride=w * 4 + 20, fill=0xA5, reference_rgba=True)   # the reference's RGBA branch as it executes
+    assert np.array_equal(ref_rgba, image_builder(gp, w, h, w * 4 + 20, alpha=alpha))
 
 
 @pytest.mark.parametrize("size", [256, 1024])
@@ -95,6 +100,43 @@ def test_gpu_encode_gpu_decode_roundtrip(hip, dec, oracle_built, size):
     cov = np.repeat(np.repeat(hip.coverage(), 4, axis=0), 4, axis=1)
     rec = np.stack([detile(dec.planes()[c], size, size) for c in range(3)]).astype(np.int64)
     assert np.abs(rec - planes[:3])[:, cov].max() <= 6
+
+
+GOLDEN_RGBA = ["mixed128_rgba", "synth256_rgba"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_RGBA + ["synth64_rgb", "twocolor64_rgb"])
+def test_decode_against_reference_fixtures(dec, name):
+    """The decode kernels fed with the REFERENCE's own streams (tests/golden, captured from the compiled reference) must reproduce
+    the reference's own outputs: tiled planes, tile4x4Mask, Decompress1BitTiled's mask (a18) and internal_imageBuilderFunc's rows
+    (a20) -- no oracle in between."""
+    import os
+    from tests.blobs import RGB_OUT_PAD, RGBA_OUT_PAD, parse_mip_chunk
+    from tests.golden.make_golden import FULL
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+    planes = FULL[name]()
+    n, h, w = planes.shape
+    counts = ref["grad_counts"].view(np.int32)
+    dec.begin(w, h)
+    for i, (sx, sy) in enumerate(PASSES):
+        if counts[i]:
+            dec.decompress_gradient(sx, sy, ref[f"grad_bitmap_{i}"], ref[f"grad_rgbdq_{i}"])
+    assert dec.planes().tobytes() == ref["dec_planes_grad"].tobytes()
+    assert dec.tile4x4().tobytes() == ref["dec_tile4x4"].tobytes()
+    dec.decompress_1d(ref["d1_type"], ref["d1_pix"])
+    assert dec.planes().tobytes() == ref["dec_planes_full"].tobytes()
+    stride = int(ref["dec_rgb_out_info"].view(np.int32)[0])
+    assert stride == w * 3 + RGB_OUT_PAD
+    assert dec.image(stride=stride, fill=0xA5).tobytes() == ref["dec_rgb_out"].tobytes()
+    if n == 4:
+        stride_a = int(ref["dec_rgba_out_info"].view(np.int32)[0])
+        assert stride_a == w * 4 + RGBA_OUT_PAD
+        got = dec.image(alpha=planes[3].astype(np.uint8), stride=stride_a, fill=0xA5, reference_rgba=True)
+        assert got.tobytes() == ref["dec_rgba_out"].tobytes()
+        bbox, level, bits = parse_mip_chunk(ref["mip_chunk"].tobytes())
+        assert level == 4
+        assert (ref["dec_mask_bbox"].view(np.int32) == np.array(bbox, np.int32) * 16).all()
+        assert dec.decompress_1bit_tiled(bits, int(bbox[2]), int(bbox[3])).tobytes() == ref["dec_mask"].tobytes()
 
 
 def test_mask_decode(dec, oracle_built):

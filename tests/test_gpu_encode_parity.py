@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from tests.images import edge_image, synth_planes
+from tests.images import edge_image, lineart_image, natural_photo, synth_planes
 from tests.parity import compare_encode
 
 pytestmark = pytest.mark.gpu
@@ -39,6 +39,47 @@ def test_photo_like_1024_bit_exact(hip, oracle_built, m3):
     """Textured content: tiles of every span, i.e. every rangeDecode slab of the quantiser table, incl. exact ties between modes."""
     bad = compare_encode(edge_image(1024, 1024, "photo", 4, seed=3), hip, m3)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("m3", [False, True])
+def test_non_synthetic_images_bit_exact(hip, oracle_built, m3):
+    """Not YAIK-synth: a procedurally drawn flat-colour illustration with anti-aliased edges and an alpha surround (the content
+    YAIK targets, 1024x1024 RGBA) and a crop of a natural photograph (256x256 RGB), corner streams included."""
+    for planes in (lineart_image(1024, 4), natural_photo()):
+        bad = compare_encode(planes, hip, m3, check_corners=True)
+        assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["lineart1024_rgba", "photo_astronaut256_rgb", "synth1024_rgba"])
+def test_gpu_outputs_match_reference_hashes(oracle_built, name):
+    """No oracle in between: SHA-256 of the HIP path's outputs against the hashes tests/golden/make_golden.py took from the compiled
+    reference's own blobs (tile bitmaps, tile definitions / nibble streams of both start modes, 1-D streams, alpha bounds)."""
+    import hashlib, json, os
+    from tests.golden.make_golden import HASHED
+    from yaik_amd.encoder import HipTileEncoder
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hashes.json")) as f:
+        want = json.load(f)[name]
+    planes = HASHED[name]()
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    e = HipTileEncoder(0)
+    try:
+        for m in (0, 1):
+            e.set_image(planes)
+            if planes.shape[0] == 4:
+                mip = e.mip_prefilter()
+                assert sha(np.array(list(mip["bounds"]) + [16, mip["remaining"]], dtype=np.int32)) == want["mip_bounds"]
+            e.encode(3, bool(m), False)
+            if m == 0:
+                for i in range(7):
+                    assert sha(e.gradient_bitmap(i)) == want[f"grad_bitmap_{i}"], i
+                assert e.gradient_counts().tolist() == want["grad_counts_values"]
+            for p in range(3):
+                defs, nib, nn = e.range_streams(p)
+                assert sha(defs) == want[f"plnt_defs_{m}_{p}"] and sha(nib) == want[f"plnt_idx_{m}_{p}"], (m, p)
+        pix, typ = e.dynamic_tile_compressor()
+        assert sha(pix) == want["d1_pix"] and sha(typ) == want["d1_type"]
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("case", ["synth256x4", "mixed128x4", "twocolor128", "noise64"])

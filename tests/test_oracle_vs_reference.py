@@ -4,7 +4,7 @@ import pytest
 
 from oracle.refrun import have_ref, run_reference
 from tests.blobs import compare_with_reference, oracle_blobs
-from tests.images import edge_image, synth_planes
+from tests.images import edge_image, lineart_image, natural_photo, synth_planes
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref/ref_driver not built (needs /root/reference)")
 
@@ -20,6 +20,8 @@ CASES = {
     "mixed200x136_rgb": lambda: edge_image(200, 136, "mixed", 3),
     "photo256_rgba": lambda: edge_image(256, 256, "photo", 4),
     "photo192x128_rgb": lambda: edge_image(192, 128, "photo", 3, seed=11),
+    "lineart512_rgba": lambda: lineart_image(512, 4),            # drawn illustration, anti-aliased edges, alpha surround
+    "photo_astronaut256_rgb": natural_photo,                     # natural photograph
 }
 
 

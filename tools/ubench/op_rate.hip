@@ -47,7 +47,21 @@
   X(42, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]", 1) \
   X(43, "v_cvt_f32_ubyte2 %0, %0", 0) \
   X(44, "v_cvt_f32_f16 %0, %0", 1) \
-  X(45, "v_dot2c_f32_f16 %0, %1, %2", 1)
+  X(45, "v_dot2c_f32_f16 %0, %1, %2", 1) \
+  X(46, "v_lshlrev_b64 %0, %1, %0", 2) \
+  X(47, "v_lshrrev_b64 %0, %1, %0", 2) \
+  X(48, "v_cmp_ne_u64 vcc, %0, %1", 2) \
+  X(49, "v_lshl_add_u64 %0, %0, 1, %1", 2) \
+  X(50, "v_and_b32 %0, %0, %1", 0) \
+  X(51, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", 1) \
+  X(52, "v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5", 0) \
+  X(53, "v_alignbit_b32 %0, %0, %1, 4", 0) \
+  X(54, "v_add_lshl_u32 %0, %0, %1, 4", 0) \
+  X(55, "v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", 0) \
+  X(56, "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2", 0) \
+  X(57, "v_dot4_u32_u8 %0, %0, %1, %2", 0) \
+  X(58, "v_dot2_u32_u16 %0, %0, %1, %2", 0) \
+  X(59, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96", 0)
 template <int KIND>
 __global__ void k(uint32_t* out, uint32_t seed, int iters) {
     uint32_t a[8]; float f[8]; uint64_t d[8];

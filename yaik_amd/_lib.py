@@ -81,6 +81,7 @@ SIGNATURES = {
     "yk_decode_planes": (C.c_int, [vp, vp, vp, vp, sz]),
     "yk_decode_planes_device": (vp, [vp, szp]),
     "yk_decode_output": (C.c_int, [vp, vp, sz, vp, C.c_int]),
+    "yk_decode_output_reference_rgba": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),

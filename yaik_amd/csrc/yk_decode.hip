@@ -246,6 +246,17 @@ __global__ __launch_bounds__(256) void yk_dec_detile_kernel(const uint8_t* __res
     }
 }
 
+// The reference's RGBA branch as it executes (decoder/YAIK_DefaultCallback.cpp:45-62): the alpha store does not advance dst, so a row is
+// w RGB triples followed by ONE alpha byte; the alpha row cursors advance w bytes per tile row instead of 8 * strideA (:36-39 vs
+// :128-130), so row y ends on the byte alpha[strideA * (y & 7) + w * (y >> 3) + w - 1].  One thread per row writes that byte.
+__global__ __launch_bounds__(256) void yk_dec_ref_alpha_kernel(const uint8_t* __restrict__ alpha, int strideA, size_t alphaBytes, int w, int h,
+                                                               uint8_t* __restrict__ out, size_t pitch) {
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    if (y >= h) return;
+    const size_t src = (size_t)strideA * (y & 7) + (size_t)w * (y >> 3) + (size_t)(w - 1);
+    out[(size_t)y * pitch + (size_t)w * 3] = src < alphaBytes ? alpha[src] : 0;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int yk_dec_scratch(yk_ctx* c, size_t bytes) {
     if (c->dScratchBytes >= bytes) return YK_OK;
@@ -372,22 +383,38 @@ int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, 
     return YK_OK;
 }
 
-int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA) {
+// Shared body of the two output entry points.  The device image is packed tight (w * bpp bytes per row) and lands in the caller's
+// buffer by a 2-D copy with dpitch = outputImageStride: like the reference's loop, bytes of a row beyond the pixels are never
+// touched (outputImageStride exists to place the image INSIDE a larger buffer, include/YAIK.h:190).
+static int yk_decode_output_impl(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA, bool refRGBA) {
     if (!c || !hostOut) return YK_ERR_BAD_ARG;
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
-    const int w = c->dw, h = c->dh, bpp = hostAlpha ? 4 : 3;
-    if (outputImageStride < (size_t)w * bpp || (hostAlpha && strideA < w)) return yk_fail(c, YK_ERR_BAD_ARG, "output stride too small");
+    const int w = c->dw, h = c->dh, bpp = (hostAlpha && !refRGBA) ? 4 : 3;
+    const size_t rowBytes = (size_t)w * bpp + (refRGBA && hostAlpha ? 1 : 0);
+    if (outputImageStride < rowBytes || (hostAlpha && strideA < w)) return yk_fail(c, YK_ERR_BAD_ARG, "output stride too small");
     YK_HIP(c, hipSetDevice(c->device));
-    const size_t outBytes = outputImageStride * h, aBytes = hostAlpha ? (size_t)strideA * h : 0, oA = (outBytes + 31) & ~(size_t)15;
+    const size_t dPitch = (rowBytes + 15) & ~(size_t)15;
+    const size_t outBytes = dPitch * h, aBytes = hostAlpha ? (size_t)strideA * h : 0, oA = (outBytes + 31) & ~(size_t)15;
     int rc = yk_dec_scratch(c, oA + aBytes + 64); if (rc) return rc;
-    if (outputImageStride != (size_t)w * bpp) YK_HIP(c, hipMemsetAsync(c->dScratch, 0, outBytes, c->stream));   // row padding
     if (hostAlpha) YK_HIP(c, hipMemcpyAsync(c->dScratch + oA, hostAlpha, aBytes, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
-                       hostAlpha ? c->dScratch + oA : (const uint8_t*)nullptr, strideA, c->dScratch, outputImageStride);
+                       (hostAlpha && !refRGBA) ? c->dScratch + oA : (const uint8_t*)nullptr, strideA, c->dScratch, dPitch);
     YK_HIP(c, hipGetLastError());
-    YK_HIP(c, hipMemcpyAsync(hostOut, c->dScratch, outBytes, hipMemcpyDeviceToHost, c->stream));
+    if (refRGBA && hostAlpha) {
+        hipLaunchKernelGGL(yk_dec_ref_alpha_kernel, dim3((h + 255) / 256), dim3(256), 0, c->stream, c->dScratch + oA, strideA, aBytes, w, h, c->dScratch, dPitch);
+        YK_HIP(c, hipGetLastError());
+    }
+    YK_HIP(c, hipMemcpy2DAsync(hostOut, outputImageStride, c->dScratch, dPitch, rowBytes, (size_t)h, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
+}
+
+int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA) {
+    return yk_decode_output_impl(c, hostOut, outputImageStride, hostAlpha, strideA, false);
+}
+
+int yk_decode_output_reference_rgba(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA) {
+    return yk_decode_output_impl(c, hostOut, outputImageStride, hostAlpha, strideA, true);
 }
 
 const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize) {

@@ -226,6 +226,12 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Cache policy of the quantiser-table gathers (experiment switch): 0 = plain global loads; n > 0 = buffer loads
+// with aux = n (1 sc0, 2 nt, 16 sc1)
+#ifndef YK2_QPOL
+#define YK2_QPOL 0
+#endif
+typedef uint32_t y2u3 __attribute__((ext_vector_type(3)));
 #define YK2_RUN 16
 // -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
 // five points, its entry time and its hardware slot (HW_ID, XCC_ID) into a device array that yk_debug_wave_times copies out.
@@ -506,6 +512,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     } else {
         uint32_t* lut = &s_lut[tw][0];
+#if YK2_QPOL != 0
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.qtab, 0, YK2_QNR * YK2_QROWS * 16, 0x00020000);
+#endif
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
 #pragma unroll
         for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __fdiv_rn(1.0f, (float)v) : 0.0f; }   // correctly rounded: the exact path needs that
@@ -574,9 +583,15 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const uint32_t v = (uint32_t)y2_byte(pw[k], p);
+#if YK2_QPOL == 0
                     const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
                     const uint32_t m03 = row[0], m45 = row[1];
                     iw[k] = row[2];
+#else
+                    const y2u3 row = __builtin_amdgcn_raw_buffer_load_b96(qrsrc, qrow + v * 16u, 0, YK2_QPOL - 1);
+                    const uint32_t m03 = row.x, m45 = row.y;
+                    iw[k] = row.z;
+#endif
                     const float rv = s_rcp[v];                                   // a table: v_rcp_f32 is a quarter-rate op, 16 per plane add up
                     sm[0] = __fmaf_rn((float)(m03 & 255u), rv, sm[0]);
                     sm[1] = __fmaf_rn((float)((m03 >> 8) & 255u), rv, sm[1]);

@@ -59,14 +59,16 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_decode_planes(self._h, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, n))
         return out
 
-    def image(self, alpha: np.ndarray | None = None, stride: int | None = None) -> np.ndarray:
-        """internal_imageBuilderFunc: interleaved RGB ([h, stride] bytes, 3 B/pixel) or RGBA when an alpha plane is given."""
+    def image(self, alpha: np.ndarray | None = None, stride: int | None = None, fill: int = 0, reference_rgba: bool = False) -> np.ndarray:
+        """internal_imageBuilderFunc: interleaved RGB ([h, stride] bytes, 3 B/pixel) or RGBA when an alpha plane is given.
+        Bytes of a row beyond the pixels keep `fill` (the call never writes them).  reference_rgba selects the reference's own
+        RGBA branch, defects included (yk_decode_output_reference_rgba)."""
         bpp = 4 if alpha is not None else 3
         stride = stride or self.w * bpp
-        out = np.zeros((self.h, stride), dtype=np.uint8)
+        out = np.full((self.h, stride), fill, dtype=np.uint8)
         a = np.ascontiguousarray(alpha, dtype=np.uint8) if alpha is not None else None
-        _chk(self._h, lib().yk_decode_output(self._h, out.ctypes.data, stride, a.ctypes.data if a is not None else None,
-                                             a.shape[1] if a is not None else 0))
+        fn = lib().yk_decode_output_reference_rgba if reference_rgba else lib().yk_decode_output
+        _chk(self._h, fn(self._h, out.ctypes.data, stride, a.ctypes.data if a is not None else None, a.shape[1] if a is not None else 0))
         return out
 
     def tile4x4(self) -> np.ndarray:

@@ -182,10 +182,10 @@ bool YAIK_DecodeImage(void* stream, uint32_t length, YAIK_SDecodedImage* info) {
             } else setError(YAIK_INVALID_STREAM);
             ua.customFree(ua.customContext, planes);
         } else {
-            // default builder = the de-tile kernel; no alpha value chunk is on this path, so an RGBA image gets opaque alpha
-            std::vector<uint8_t> alpha;
-            if (s->isRGBA) alpha.assign((size_t)w * h, 255);
-            res = yk_decode_output(s->ctx, info->outputImage, (size_t)info->outputImageStride, s->isRGBA ? alpha.data() : nullptr, w) == YK_OK;
+            // default builder = the de-tile kernel.  The alpha value chunk ('ALPM') is not on this path, so like the reference's
+            // pCtx->alphaChannel the alpha plane is NULL and internal_imageBuilderFunc takes its RGB branch (3 B/pixel) whether or
+            // not the header says RGBA (YAIK_API.cpp:1316, YAIK_DefaultCallback.cpp:44,63); row padding is left untouched.
+            res = yk_decode_output(s->ctx, info->outputImage, (size_t)info->outputImageStride, nullptr, w) == YK_OK;
             if (!res) setError(YAIK_INVALID_STREAM);
         }
     } while (false);
