@@ -3,6 +3,12 @@
 8x8 4-bpp range quantiser of 3 planes) on an 8192x8192 RGBA frame of synthetic "YAIK-synth v1" data, inputs resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--mode3] [--in-flight F] [--no-cpu] [--no-parity]
+                  [--stage encode|corners|range1d|decode] [--layout frames|stripes]
+
+Default (--stage encode --layout frames) is the headline line described below.  --stage corners | range1d | decode time the other
+stages of the path on the same frame (corner-colour streams, live 1-D range path, GPU decode) and print a `roofline` for the
+stage's dominant kernel; --layout stripes (N > 1) encodes ONE image as row stripes: stripe bbox all-reduce, one RCCL gather of the
+tile maps, checked against a whole-image encode on rank 0 (strong scaling).
 
 One "step" = one pass of the hot path over a batch of F frames per GPU kept in flight on F handles/streams (--in-flight F, default 2:
 the HBM-bound alpha / pack kernels of one frame run under the VALU-bound fused kernel of the other; --in-flight 1 = one frame at a time):
@@ -28,6 +34,262 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
+def kernel_source_hash() -> str:
+    import hashlib
+    with open(os.path.join(ROOT, "yaik_amd", "csrc", "yk_encode2.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def _timed(steps, warmup, step, fence, world, dist, comm_dev):
+    """W untimed steps, then exactly K steps between two fences (barrier + synchronize); returns the MAX over ranks of the elapsed time."""
+    import torch
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
+    """--stage corners | range1d | decode: the stages of the path outside the headline encode, one frame of --size per rank (replicas for
+    N > 1: these stages shard like the encode, no collective).  `value` is the stage's whole-call rate including what its C-ABI entry
+    point does on the host side (stream sizes read back, and for decode the host->device copies of the streams and the image coming
+    back, as the YAIK.h boundary hands over host buffers); `roofline` is the dominant kernel alone, event-timed on the launch stream."""
+    import numpy as np
+    import torch
+    from yaik_amd.decoder import HipTileDecoder
+    from yaik_amd.encoder import HipTileEncoder
+    from yaik_amd.synth import synth_planes_torch
+    W = args.size
+    planes = synth_planes_torch(W, n_planes=4, seed=12345 + rank, device=dev)
+    torch.cuda.synchronize()
+    enc = HipTileEncoder(dev_index)
+    enc.set_image(planes)
+    enc.alpha_reject(); enc.alpha_finish(None)
+    enc.encode(3, args.mode3, False)
+    enc.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        enc.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    ST = {"corners": (0,), "range1d": (1, 2), "decode": (3, 4, 5)}[args.stage]
+    dec = None
+    if args.stage == "corners":
+        step = enc.gradient_corners_run
+    elif args.stage == "range1d":
+        step = lambda: lib_call(enc)
+    else:
+        # streams for the decoder come from the GPU encoder: tile bitmaps, corner streams (de-quantised like PaletteFullRangeRemapping,
+        # decoder/YAIK_GenericFunctions.cpp:128-137: v * ((255 << 16) / 250) >> 16) and the 1-D streams
+        bitmaps = [enc.gradient_bitmap(i) for i in range(7)]
+        inv = (255 << 16) // 250
+        corners = [((enc.gradient_corners(i).astype(np.uint32) * inv) >> 16).astype(np.uint8) for i in range(7)]
+        counts = enc.gradient_counts()
+        pix, typ = enc.dynamic_tile_compressor()
+        dec = HipTileDecoder(dev_index)
+        out = np.zeros((W, W * 3), dtype=np.uint8)
+        shapes = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]
+
+        def step():
+            dec.begin(W, W)
+            for i, (sx, sy) in enumerate(shapes):
+                if counts[i]:
+                    dec.decompress_gradient(sx, sy, bitmaps[i], corners[i])
+            dec.decompress_1d(typ, pix)
+            dec.image_into(out)
+
+    def lib_call(e):
+        from yaik_amd._lib import lib
+        from yaik_amd.encoder import _chk
+        _chk(e._h, lib().yk_range1d_encode(e._h))
+
+    timer = dec if dec is not None else enc
+    for _ in range(args.warmup):
+        step()
+    for st in ST:
+        timer.stage_ms(st)                                   # drop the warm-up intervals
+    elapsed = _timed(args.steps, 0, step, fence, world, dist, comm_dev)
+    ms = {st: timer.stage_ms(st) for st in ST}
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    per = {st: (ms[st][0] / max(1, args.steps)) for st in ST}  # kernel ms per step
+    nd_nn = [enc.range_streams(p) for p in range(3)]
+    cov = enc.coverage()
+    uncovered = int((~cov).sum()) * 16                       # pixels the gradient passes left to the 1-D path
+    bitmap_bytes = sum(enc.gradient_bitmap(p).size for p in range(7))
+    if args.stage == "corners":
+        lat = (W // 4 + 1) ** 2
+        nb = sum(enc.gradient_corners(i).size for i in range(7))
+        alg = bitmap_bytes + 4 * lat * 2 + 4 * nb            # bitmaps read + lattice owner cleared and resolved (4 B per point, twice) + 3 B read as 3 samples (12 B) / 3 B written per colour
+        alg = bitmap_bytes + 8 * lat + 5 * nb
+        kname, kms, note = "yk_corner_* (lattice clear + owner + count + scan + emit, 7 passes)", per[0], "sparse scatter / gather: latency- and atomics-bound, far from the HBM roof by construction"
+    elif args.stage == "range1d":
+        pixn = uncovered * 3
+        alg = 12 * W * W + pixn + 64 * 0 + (W // 8) * (W // 8) * 3 * 3     # three int32 planes read once + 1 B per uncovered pixel and plane + 3 parameter bytes per tile-plane
+        kname, kms, note = "yk_range1d_kernel", per[1], f"scan + pack kernels: {per[2]:.4f} ms per frame on top"
+    else:
+        pixn = uncovered * 3
+        alg = pixn + 3 * W * W                              # yk_dec1d_kernel: 1 B per uncovered pixel and plane read + the pixels it writes (<= 3 B/pixel); the dominant decode kernel by bytes
+        alg = 2 * pixn + (W // 8) * (W // 8) * 9
+        kname, kms = "yk_dec1d_kernel (+ count / scan kernels)", per[4]
+        note = (f"other decode kernels per frame: gradient owner/corner/render x{ms[3][1] // max(1, args.steps)} passes {per[3]:.4f} ms, "
+                f"yk_dec_detile_kernel {per[5]:.4f} ms (6 B/pixel moved = {6 * W * W / (per[5] * 1e-3) / 1e9 if per[5] > 0 else 0:.0f} GB/s)")
+    achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    result = {
+        "metric": f"Mpix/s {args.stage} stage, 8K RGBA frame" if W == 8192 else f"Mpix/s {args.stage} stage, {W}x{W} RGBA frame",
+        "value": round(W * W * world * args.steps / 1e6 / elapsed, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/int32", "data": "synthetic (YAIK-synth v1, seed 12345+rank)",
+        "config": {"workload": f"{W}x{W} RGBA frame per GPU, stage '{args.stage}' of the tile path after a full encode; a step is one call sequence through the "
+                               "C-ABI incl. its host-side part (decode: host streams in, interleaved RGB image out over PCIe)",
+                   "parallelism": f"replicas x{world} (no collective)" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": kname, "kernel_ms": round(kms, 4), "algorithmic_bytes": int(alg), "note": note},
+    }
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) -> int:
+    """--layout stripes: ONE --size x --size RGBA image, rank r owns a band of 64-row blocks (+ 1 halo row it reads but does not own).
+    Per step: alpha reject on the stripe -> stripe bbox -> two tiny all-reduces (image-wide kept-tile box) -> alpha finish -> fused
+    encode + compaction -> export -> ONE gather of the tile maps onto rank 0 (double-buffered: the transfer of step i rides under the
+    kernels of step i+1).  Outside the timed region rank 0 encodes the whole image itself and checks that the gathered stripes
+    concatenate to it bit for bit (bitmaps, tile definitions, nibble streams)."""
+    import numpy as np
+    import torch
+    from yaik_amd import distributed as ykd
+    from yaik_amd.encoder import HipTileEncoder
+    from yaik_amd.synth import synth_planes_torch
+    W = args.size
+    y0, h, halo = ykd.stripe_rows(W, world, rank)
+    enc = None
+    if h:
+        stripe = synth_planes_torch(W, W, n_planes=4, seed=12345, device=dev, row0=y0, rows=h + halo)
+        torch.cuda.synchronize()
+        enc = HipTileEncoder(dev_index)
+        enc.set_image(stripe, full_h=W, y0=y0, halo_rows=halo)
+    cap = torch.tensor([enc.export_capacity() if enc else 0], dtype=torch.int64, device=comm_dev)
+    if world > 1:
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    pipe = ykd.TileMapGatherPipeline(dist, comm_dev, int(cap.item()), dst=0, staging_device=dev) if world > 1 else None
+    empty_sizes = np.zeros(15, dtype=np.int64)
+
+    def step():
+        box = np.array(ykd.EMPTY_BBOX, dtype=np.int32)
+        if enc:
+            enc.alpha_reject()
+            box = enc.stripe_bbox()
+        gb = ykd.allreduce_bbox(box, dist, comm_dev) if world > 1 else box
+        if enc:
+            enc.alpha_finish(gb)
+            enc.encode(3, args.mode3, False)
+        if world > 1:
+            blob, _ = pipe.acquire()
+            if enc:
+                sizes = enc.export_tile_maps(blob)
+                pipe.submit(int(sizes[14]), sizes)
+            else:
+                pipe.submit(0, empty_sizes)                  # a rank without rows still joins the gather, with an empty payload
+
+    def fence():
+        torch.cuda.synchronize()
+        if enc:
+            enc.synchronize()
+        if world > 1:
+            pipe.flush()
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if enc and args.warmup:
+        enc.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kms = enc.kernel_ms() if enc else {"encode": 0.0, "alpha": 0.0, "pack": 0.0}
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- outside the timed region: one more gather, checked on rank 0 against a whole-image encode ----
+    gather_check = None
+    if world > 1:
+        blob, _ = pipe.acquire()
+        if enc:
+            sizes = enc.export_tile_maps(blob)
+            pipe.submit(int(sizes[14]), sizes)
+        else:
+            pipe.submit(0, empty_sizes)
+        res = pipe.flush()[-1]
+        if rank == 0:
+            if W > 16384:
+                gather_check = "skipped (whole image too large for one reference encode)"
+            else:
+                whole = HipTileEncoder(dev_index)
+                whole.set_image(synth_planes_torch(W, n_planes=4, seed=12345, device=dev))
+                whole.alpha_reject(); whole.alpha_finish(None)
+                whole.encode(3, args.mode3, False)
+                parts = [ykd.split_blob(sz, payload) for sz, payload in res if int(sz[14])]
+                bad = []
+                for i in range(7):
+                    if not np.array_equal(np.concatenate([p["bitmaps"][i] for p in parts]), whole.gradient_bitmap(i)):
+                        bad.append(f"bitmap {i}")
+                for pl in range(3):
+                    d, nb, nn = whole.range_streams(pl)
+                    if not np.array_equal(np.concatenate([p["defs"][pl] for p in parts]), d):
+                        bad.append(f"defs {pl}")
+                    cat, total = ykd.concat_nibble_streams([p["nibbles"][pl] for p in parts], [p["n_nibbles"][pl] for p in parts])
+                    if total != nn or not np.array_equal(cat, nb):
+                        bad.append(f"nibbles {pl}")
+                whole.close()
+                gather_check = "ok: gathered stripes == whole-image encode (7 bitmaps, 3x tile defs, 3x nibble streams)" if not bad else "MISMATCH " + ", ".join(bad)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    nblocks = (W + 63) // 64
+    result = {
+        "metric": "Mpix/s tile encode (alpha reject + 7 gradient passes + 8x8 range quant), 8K RGBA" if W == 8192 else
+                  f"Mpix/s tile encode (alpha reject + 7 gradient passes + 8x8 range quant), {W}x{W} RGBA",
+        "value": round(W * W * args.steps / 1e6 / elapsed, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8/int32 (+f32 mode-selection sums)", "data": "synthetic (YAIK-synth v1, seed 12345)",
+        "config": {"workload": f"ONE {W}x{W} RGBA image per step, full encode ({'3' if args.mode3 else '4'}-bpp range), inputs resident in HBM",
+                   "layout": "row stripes", "stripe_rows_rank0": int(h), "blocks_of_64_rows": nblocks,
+                   "parallelism": (f"row stripes x{world}: stripe bbox all-reduce (2 x 2 ints) + ONE gather of the tile maps per image"
+                                   if world > 1 else "single GPU (whole image = one stripe)"),
+                   "collective_backend": (dist.get_backend() if world > 1 else None), "collective_world_size": (dist.get_world_size() if world > 1 else 1)},
+        "rank0_kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+    }
+    if gather_check is not None:
+        result["gather_check"] = gather_check
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if (gather_check is None or not gather_check.startswith("MISMATCH")) else 1
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +305,11 @@ def main() -> int:
                     "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
                     "frames, where the ~8 stream operations per frame are what limits the rate; per-kernel times are then one interval")
+    ap.add_argument("--stage", choices=["encode", "corners", "range1d", "decode"], default="encode", help="which stage of the path a step runs: encode = the "
+                    "headline (alpha reject + fused gradient/range kernel + compaction); corners = the seven corner-colour streams (a6 rgbStream); "
+                    "range1d = the live 1-D range path (a15); decode = gradient + 1-D decode + de-tile on the GPU (a16, a17, a20)")
+    ap.add_argument("--layout", choices=["frames", "stripes"], default="frames", help="N > 1: frames = every rank encodes its own frames (weak scaling, "
+                    "default); stripes = ONE image of --size, rank r owns a band of 64-row blocks + 1 halo row (strong scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size bit-exactness check against the oracle")
     ap.add_argument("--cpu-size", type=int, default=0, help="side of the centred crop timed on the CPU (default: whole frame)")
@@ -79,6 +346,11 @@ def main() -> int:
             dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.stage != "encode":
+        return bench_stage(args, rank, world, dist, dev, dev_index, comm_dev)
+    if args.layout == "stripes":
+        return bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal)
 
     W = args.size
     K = max(1, args.in_flight)
@@ -223,13 +495,18 @@ def main() -> int:
     alg_bytes = 12 * W * W + bitmap_bytes + out_bytes            # 4 B x 3 planes read once + bitmaps + defs + nibbles
     achieved = alg_bytes / (kms["encode"] * 1e-3) / 1e9 if kms["encode"] > 0 else 0.0
     # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh); only valid for the default workload
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/profile_round.sh writes profiles/traffic.json with the
+    # SHA-256 of the kernel source it measured): reported only while that hash matches the kernel source in this tree, else null
     traffic, traffic_src = None, None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     if os.path.exists(tpath) and W == 8192 and not args.mode3 and K <= 2 and not BF:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("kernel") == "yk_encode2_kernel":
-            traffic, traffic_src = int(tj["hbm_traffic_bytes"]), tj.get("source")
+            if tj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic, traffic_src = int(tj["hbm_traffic_bytes"]), tj.get("source")
+            else:
+                traffic_src = "stale: profiles/traffic.json was measured on another version of yk_encode2.hip (re-run tools/profile_round.sh)"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
@@ -276,8 +553,9 @@ def main() -> int:
             host = planes.cpu().numpy()
         ora = pyoracle.OracleEncoder(host)
         c0 = time.perf_counter()
-        ora.mip_prefilter()
-        obm = [ora.fitting_quad_smooth(sx, sy)[1] for sx, sy in pyoracle.PASSES]
+        omip = ora.mip_prefilter()
+        ograd = [ora.fitting_quad_smooth(sx, sy) for sx, sy in pyoracle.PASSES]
+        obm = [g[1] for g in ograd]
         orng = [ora.dynamic_tile_encode(p, args.mode3)[:3] for p in range(3)]
         c1 = time.perf_counter()
         if not args.no_cpu:
@@ -296,7 +574,13 @@ def main() -> int:
             for p in range(3):
                 d, nb, nn = nd_nn[p]
                 ok &= np.array_equal(d, orng[p][0]) and np.array_equal(nb, orng[p][1]) and nn == orng[p][2]
-            result["parity"] = "bit-exact vs oracle at full size (7 bitmaps, 3x tile defs, 3x nibble streams)" if ok else "MISMATCH"
+            ga = enc.alpha_result()                         # alpha tile-reject: bounds, kept pixels, tile box and the 1-bit bitmap
+            ok &= bool(ga["has_chunk"]) == bool(omip["has_chunk"]) and np.array_equal(ga["bounds"], omip["bounds"]) and int(ga["remaining"]) == int(omip["remaining"])
+            if omip["has_chunk"]:
+                ok &= np.array_equal(ga["tile_bbox"], omip["tile_bbox"]) and np.array_equal(ga["bitmap"], omip["bitmap"])
+            ok &= all(np.array_equal(enc.gradient_corners(i), ograd[i][2]) for i in range(7))      # corner-colour streams of the 7 passes
+            result["parity"] = ("bit-exact vs oracle at full size (alpha reject bitmap + bounds, 7 tile bitmaps, 7 corner streams, 3x tile defs, "
+                                "3x nibble streams)") if ok else "MISMATCH"
             if not ok:
                 print(json.dumps(result))
                 return 1

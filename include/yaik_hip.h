@@ -116,7 +116,8 @@ int yk_select_frame(yk_ctx* c, int frame);
  * the other.  Two fused kernels sharing the chip only slow each other down, so a caller that alternates handles can order them:
  * the NEXT yk_encode_tiles of c launches its fused kernel after the fused kernel most recently launched on `other` has finished
  * (a stream-wait on an event, no host synchronisation; the alpha stage and the compaction of c are not held back).  Same device;
- * `other` must stay alive until that yk_encode_tiles of c has been issued (the event belongs to it). */
+ * `other` must stay alive until that encode of c has been issued (the event belongs to it).  The request is consumed by the next
+ * yk_encode_tiles / yk_encode_batch / yk_encode_frame of c (the last one holds its whole replay back) and dropped by yk_set_image. */
 int yk_order_fused_after(yk_ctx* c, const yk_ctx* other);
 
 /* gradient results (valid after yk_encode_tiles) -------------------------------------------------
@@ -133,6 +134,8 @@ int    yk_coverage(yk_ctx* c, uint16_t* hostOut, size_t capElems);
 /* corner-colour stream of pass p = `rgbStream` (:4113-4132): CompressF(Round6(corner),250) bytes of every corner
  * not yet in `mappedRGB`, in scan order, de-duplicated across passes.  Call for p = 0..6 in order. */
 int    yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap, size_t* nBytes);
+/* (re)builds the seven corner streams on the device without copying anything out (yk_gradient_corners does it on first use) */
+int    yk_gradient_corners_run(yk_ctx* c);
 /* Row stripes (new; SURVEY §8e "corner dedup across stripe-boundary lattice rows ... on the root"): a stripe handle
  * de-duplicates inside its own rows, but its first and last lattice rows (y = y0 and y = y0 + h) are shared with the
  * neighbouring stripes.  For those two rows, n = w/4 + 1 points each (first row, then last row): keys[i] = the stripe-local
@@ -224,6 +227,16 @@ int yk_set_kernel_version(yk_ctx* c, int version);
  * dropped), so a caller can queue many frames back to back and read the per-kernel times once, without a sync per frame.
  * Synchronises with the most recent encode. */
 int yk_last_kernel_ms(yk_ctx* c, float* fusedEncodeMs, float* alphaMs, float* packMs);
+/* Device time of the stages outside the fused encode, from HIP events recorded on the launch stream around the stage's KERNELS
+ * (host<->device copies of the decode entry points are outside the intervals).  Returns the sum of the intervals recorded since
+ * the last query of that stage and their number, and resets both. */
+enum { YK_STAGE_CORNERS = 0,       /* yk_gradient_corners: lattice clear + owner / count / scan / emit kernels of the 7 passes */
+       YK_STAGE_RANGE1D = 1,       /* yk_range1d_encode: yk_range1d_kernel (the dominant kernel of the live 1-D path) */
+       YK_STAGE_RANGE1D_PACK = 2,  /* yk_range1d_encode: scans + yk_range1d_pack_kernel */
+       YK_STAGE_DEC_GRADIENT = 3,  /* yk_decode_gradient: owner / corner / scan / render kernels of one pass per interval */
+       YK_STAGE_DEC_1D = 4,        /* yk_decode_1d: count / scans / yk_dec1d_kernel */
+       YK_STAGE_DEC_DETILE = 5 };  /* yk_decode_output: yk_dec_detile_kernel */
+int yk_stage_ms(yk_ctx* c, int stage, float* msSum, int* intervals);
 
 #ifdef __cplusplus
 }

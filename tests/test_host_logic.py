@@ -95,7 +95,7 @@ def test_synth_generators_agree():
 
 def test_stripe_partition_and_stream_concatenation():
     from yaik_amd import distributed as ykd
-    for full_h, world in ((16384, 8), (8192, 8), (4096, 3), (2048, 5), (64, 4), (200 * 8, 7)):
+    for full_h, world in ((16384, 8), (8192, 8), (4096, 3), (2048, 5), (1024, 5), (64, 4), (200 * 8, 7)):
         rows = [ykd.stripe_rows(full_h, world, r) for r in range(world)]
         y = 0
         for y0, h, halo in rows:
@@ -105,6 +105,12 @@ def test_stripe_partition_and_stream_concatenation():
                 assert halo == (1 if y0 + h < full_h else 0)
                 assert h % 64 == 0 or y0 + h == full_h
         assert y == full_h
+        blocks = (full_h + 63) // 64
+        if blocks >= world:
+            assert all(h >= 8 for _, h, _ in rows), (full_h, world, rows)      # nobody is left without rows while there are enough blocks
+            assert max(h for _, h, _ in rows) - min(h for _, h, _ in rows) <= 64
+        else:
+            assert [ykd.stripe_is_empty(full_h, world, r) for r in range(world)] == [r >= blocks for r in range(world)]
     assert ykd.combine_bboxes([[9999999, 9999999, -1, -1], [32, 64, 200, 128], [16, 256, 100, 300]]).tolist() == [16, 64, 200, 300]
     # nibble streams of stripes concatenate into the image-wide stream even across odd boundaries
     rng = np.random.default_rng(1)

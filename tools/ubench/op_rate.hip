@@ -48,10 +48,10 @@
   X(43, "v_cvt_f32_ubyte2 %0, %0", 0) \
   X(44, "v_cvt_f32_f16 %0, %0", 1) \
   X(45, "v_dot2c_f32_f16 %0, %1, %2", 1) \
-  X(46, "v_lshlrev_b64 %0, %1, %0", 2) \
-  X(47, "v_lshrrev_b64 %0, %1, %0", 2) \
+  X(46, "v_lshlrev_b64 %0, %1, %0", 3) \
+  X(47, "v_lshrrev_b64 %0, %1, %0", 3) \
   X(48, "v_cmp_ne_u64 vcc, %0, %1", 2) \
-  X(49, "v_lshl_add_u64 %0, %0, 1, %1", 2) \
+  X(49, "v_lshl_add_u64 %0, %0, 1, %2", 3) \
   X(50, "v_and_b32 %0, %0, %1", 0) \
   X(51, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", 1) \
   X(52, "v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5", 0) \
@@ -72,7 +72,7 @@ __global__ void k(uint32_t* out, uint32_t seed, int iters) {
         for (int r = 0; r < 16; r++)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-#define X(N, S, F) if (KIND == N) { if (F == 1) asm volatile(S : "+v"(f[i]) : "v"(fb), "v"(fc) : "vcc"); else if (F == 2) asm volatile(S : "+v"(d[i]) : "v"(db), "v"(db) : "vcc"); else asm volatile(S : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"); }
+#define X(N, S, F) if (KIND == N) { if (F == 1) asm volatile(S : "+v"(f[i]) : "v"(fb), "v"(fc) : "vcc"); else if (F == 2) asm volatile(S : "+v"(d[i]) : "v"(db), "v"(db) : "vcc"); else if (F == 3) asm volatile(S : "+v"(d[i]) : "v"(b), "v"(db) : "vcc"); else asm volatile(S : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"); }
                 OPS(X)
 #undef X
             }

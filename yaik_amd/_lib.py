@@ -80,6 +80,8 @@ SIGNATURES = {
     "yk_decode_mask": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, sz]),
     "yk_decode_planes": (C.c_int, [vp, vp, vp, vp, sz]),
     "yk_decode_planes_device": (vp, [vp, szp]),
+    "yk_gradient_corners_run": (C.c_int, [vp]),
+    "yk_stage_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), ip]),
     "yk_decode_output": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_output_reference_rgba": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),

@@ -68,7 +68,7 @@ static int yk_alloc_image(yk_ctx* c) {
     fs.blockN = (size_t)c->nScanBlocks * 2;
     YK_HIP(c, hipMalloc(&B.blockSums, fs.blockN * F * sizeof(uint32_t)));
     YK_HIP(c, hipMalloc(&B.blockCnt, fs.blockN * F * sizeof(uint32_t)));
-    YK_HIP(c, hipMemsetAsync(B.blockCnt, 0, fs.blockN * F * sizeof(uint32_t), c->stream));   // kept zero between frames by the scan
+    YK_HIP(c, hipMemset(B.blockCnt, 0, fs.blockN * F * sizeof(uint32_t)));                   // synchronous (allocation time); kept zero between frames by the scan
     YK_HIP(c, hipMalloc(&B.totals, 8 * sizeof(uint32_t) * F));
     fs.defsOut = 3 * T8;
     YK_HIP(c, hipMalloc(&B.defsOut, fs.defsOut * F * sizeof(uint16_t) + 16));
@@ -80,7 +80,42 @@ static int yk_alloc_image(yk_ctx* c) {
     return YK_OK;
 }
 
+static int yk_stage_fold(yk_ctx* c, int st) {               // waits for the recorded intervals of a stage and adds them up
+    for (int k = 0; k < c->stN[st]; k++) {
+        float t = 0;
+        YK_HIP(c, hipEventSynchronize(c->stEv[st][k][1]));
+        YK_HIP(c, hipEventElapsedTime(&t, c->stEv[st][k][0], c->stEv[st][k][1]));
+        c->stAcc[st] += t; c->stCalls[st]++;
+    }
+    c->stN[st] = 0;
+    return YK_OK;
+}
+int yk_stage_begin(yk_ctx* c, int st) {
+    if (st < 0 || st >= YK_NUM_STAGES) return YK_ERR_BAD_ARG;
+    if (c->stN[st] == YK_STAGE_RING) { int rc = yk_stage_fold(c, st); if (rc) return rc; }
+    hipEvent_t* ev = c->stEv[st][c->stN[st]];
+    for (int i = 0; i < 2; i++) if (!ev[i]) YK_HIP(c, hipEventCreate(&ev[i]));
+    YK_HIP(c, hipEventRecord(ev[0], c->stream));
+    return YK_OK;
+}
+int yk_stage_end(yk_ctx* c, int st) {
+    if (st < 0 || st >= YK_NUM_STAGES) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipEventRecord(c->stEv[st][c->stN[st]][1], c->stream));
+    c->stN[st]++;
+    return YK_OK;
+}
+
 extern "C" {
+
+int yk_stage_ms(yk_ctx* c, int stage, float* msSum, int* intervals) {
+    if (!c || stage < 0 || stage >= YK_NUM_STAGES) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    int rc = yk_stage_fold(c, stage); if (rc) return rc;
+    if (msSum) *msSum = (float)c->stAcc[stage];
+    if (intervals) *intervals = c->stCalls[stage];
+    c->stAcc[stage] = 0; c->stCalls[stage] = 0;
+    return YK_OK;
+}
 
 int yk_device_count(void) {
     int n = 0;
@@ -114,6 +149,7 @@ void yk_destroy(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
+    for (int st = 0; st < YK_NUM_STAGES; st++) for (int k = 0; k < YK_STAGE_RING; k++) for (int i = 0; i < 2; i++) if (c->stEv[st][k][i]) (void)hipEventDestroy(c->stEv[st][k][i]);
     if (c->frameGraph) (void)hipGraphExecDestroy(c->frameGraph);
     if (c->evHandoff) (void)hipEventDestroy(c->evHandoff);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -124,7 +160,15 @@ const char* yk_last_error(const yk_ctx* c) { return c ? c->err.c_str() : "null h
 
 int yk_set_stream(yk_ctx* c, void* s) {
     if (!c) return YK_ERR_BAD_ARG;
-    c->stream = s ? (hipStream_t)s : c->ownStream;
+    hipStream_t next = s ? (hipStream_t)s : c->ownStream;
+    if (next == c->stream) return YK_OK;
+    // Work already queued on the old stream (uploads, the clears of yk_set_image, an encode) must stay ordered before whatever the
+    // caller queues on the new one: the new stream waits, on the device, for an event recorded on the old stream.
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->evHandoff) YK_HIP(c, hipEventCreateWithFlags(&c->evHandoff, hipEventDisableTiming));
+    YK_HIP(c, hipEventRecord(c->evHandoff, c->stream));
+    YK_HIP(c, hipStreamWaitEvent(next, c->evHandoff, 0));
+    c->stream = next;
     return YK_OK;
 }
 
@@ -143,6 +187,7 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
     if (y0 + h < fullH && ((h & 63) || haloRows != 1)) return yk_fail(c, YK_ERR_BAD_ARG, "inner stripes need h % 64 == 0 and one halo row");
     if (y0 + h == fullH && haloRows != 0) return yk_fail(c, YK_ERR_BAD_ARG, "the last stripe has no halo row");
     YK_HIP(c, hipSetDevice(c->device));
+    c->fusedAfter = nullptr;                                                 // an ordering request never outlives the image it was made for
     if (c->fullW == fullW && c->fullH == fullH && c->nPlanes == nPlanes && c->y0 == y0 && c->h == h && c->halo == haloRows && c->tileCount) {
         c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false;
         return YK_OK;
@@ -393,6 +438,7 @@ int yk_encode_batch(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
     if (c->nPlanes == 4) rc = yk_launch_alpha(c, true);                     // every frame's bbox kernel publishes its own bounds[0..4]
     if (rc) return rc;
     YK_HIP(c, hipEventRecord(ev[1], c->stream));
+    if (c->fusedAfter) { YK_HIP(c, hipStreamWaitEvent(c->stream, c->fusedAfter, 0)); c->fusedAfter = nullptr; }   // yk_order_fused_after
     YK_HIP(c, hipEventRecord(ev[2], c->stream));
     rc = yk_launch_encode(c, rejectFactor, mode3BitOnly, 0, true); if (rc) return rc;
     YK_HIP(c, hipEventRecord(ev[3], c->stream));
@@ -432,6 +478,7 @@ int yk_encode_frame(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
         memcpy(c->frameGraphKey, key, sizeof key);
     }
     hipEvent_t* ev = c->evRing[c->evHead % YK_EV_RING];                     // one interval for the whole frame (reported as "encode")
+    if (c->fusedAfter) { YK_HIP(c, hipStreamWaitEvent(c->stream, c->fusedAfter, 0)); c->fusedAfter = nullptr; }   // yk_order_fused_after: the whole replay waits
     YK_HIP(c, hipEventRecord(ev[0], c->stream)); YK_HIP(c, hipEventRecord(ev[1], c->stream)); YK_HIP(c, hipEventRecord(ev[2], c->stream));
     YK_HIP(c, hipGraphLaunch(c->frameGraph, c->stream));
     YK_HIP(c, hipEventRecord(ev[3], c->stream)); YK_HIP(c, hipEventRecord(ev[4], c->stream));

@@ -11,6 +11,8 @@
 #define YK_LROWS    65
 #define YK_EV_RING  64
 #define YK_SLOT     32      // bytes of nibble slot per 8x8 tile-plane (64 nibbles)
+#define YK_NUM_STAGES 6     // YK_STAGE_* of include/yaik_hip.h
+#define YK_STAGE_RING 16
 
 // Batches: one handle can hold nFrames images of one shape; every per-image array is allocated nFrames times back to back and
 // the batch kernels address frame f at base + f * stride (elements of the array's own type).
@@ -111,6 +113,10 @@ struct yk_ctx {
     unsigned evHead = 0, evTail = 0;      // sets [evTail, evHead) hold a completed encode; evCur = evHead % YK_EV_RING is being filled
     bool evAlphaInCur = false;
     float msEncode = 0, msAlpha = 0, msPack = 0;
+    // stage timers (yk_stage_ms): HIP events around the kernel sections of the stages outside the fused encode, on the launch stream
+    hipEvent_t stEv[YK_NUM_STAGES][YK_STAGE_RING][2] = {};
+    int stN[YK_NUM_STAGES] = {};                 // event pairs recorded since the last fold
+    double stAcc[YK_NUM_STAGES] = {}; int stCalls[YK_NUM_STAGES] = {};
     int ablate = 0;
     // whole-frame graph (yk_encode_frame): the stream operations of alpha stage + fused kernel + compaction, captured once per
     // (planes, shape, arguments) and replayed with one launch — for batches of small frames, where launches dominate
@@ -124,6 +130,8 @@ int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
 
 // launchers implemented in the kernel TUs
 void yk_rebase(yk_ctx* c, int frame);                    // point the working pointers at `frame`
+int yk_stage_begin(yk_ctx* c, int stage);                // records the begin event of a new interval of `stage` on c->stream
+int yk_stage_end(yk_ctx* c, int stage);
 int yk_launch_alpha(yk_ctx* c, bool batch = false);
 int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
 int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch = false);

@@ -110,6 +110,7 @@ int yk_launch_corners(yk_ctx* c) {
     if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
     uint32_t* totalDev = c->cornerScratch + nbTot;
     if (!c->cornerEdgeIdx) YK_HIP(c, hipMalloc(&c->cornerEdgeIdx, (size_t)latW * 2 * 4));
+    { int rc = yk_stage_begin(c, YK_STAGE_CORNERS); if (rc) return rc; }
     YK_HIP(c, hipMemsetAsync(c->cornerEdgeIdx, 0xFF, (size_t)latW * 2 * 4, c->stream));
     YK_HIP(c, hipMemsetAsync(c->latticeOwner, 0xFF, lat * 4, c->stream));
     for (int p = 0; p < 7; p++) {
@@ -130,6 +131,7 @@ int yk_launch_corners(yk_ctx* c) {
         blockSums += nb;
     }
     YK_HIP(c, hipGetLastError());
+    { int rc = yk_stage_end(c, YK_STAGE_CORNERS); if (rc) return rc; }
     uint32_t totals[7];
     YK_HIP(c, hipMemcpyAsync(totals, totalDev, sizeof totals, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
@@ -152,6 +154,13 @@ extern "C" int yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t
         }
     }
     return YK_OK;
+}
+
+extern "C" int yk_gradient_corners_run(yk_ctx* c) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    return yk_launch_corners(c);
 }
 
 extern "C" int yk_gradient_corner_edges(yk_ctx* c, uint32_t* hostKeys, uint32_t* hostIndex, size_t capElems) {

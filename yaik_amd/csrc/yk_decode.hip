@@ -317,6 +317,7 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     const uint32_t* bm = reinterpret_cast<const uint32_t*>(S + oB);
     uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oBB);
     uint32_t* total = reinterpret_cast<uint32_t*>(S + oT);
+    { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
     hipLaunchKernelGGL(yk_dec_owner_kernel, dim3((unsigned)((nBits + 255) / 256)), dim3(256), 0, c->stream, bm, nBits, g, w, h, latW, c->dLoaded, c->dLatticeOwner);
     hipLaunchKernelGGL(yk_dec_corner_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nBits, g, w, h, latW, c->dLoaded, c->dLatticeOwner,
                        blockSums, (const uint8_t*)nullptr, (size_t)0, (uint8_t*)nullptr);
@@ -326,6 +327,7 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     hipLaunchKernelGGL(yk_dec_render_kernel, dim3((unsigned)nWords), dim3(256), 0, c->stream, bm, nWords, g, w, h, latW, c->dMapRGB, c->dPlanes, c->dPlaneSize,
                        w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
     YK_HIP(c, hipGetLastError());
+    { int rc2 = yk_stage_end(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
     YK_HIP(c, hipStreamSynchronize(c->stream));            // the host buffers may be reused by the caller
     return YK_OK;
 }
@@ -345,6 +347,7 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
     uint32_t* cT = reinterpret_cast<uint32_t*>(S + oCT); uint32_t* cP = reinterpret_cast<uint32_t*>(S + oCP);
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
+    { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP);
     hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
     hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
@@ -353,6 +356,7 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
     hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
                        S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize);
     YK_HIP(c, hipGetLastError());
+    { int rc2 = yk_stage_end(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
 }
@@ -397,9 +401,11 @@ static int yk_decode_output_impl(yk_ctx* c, uint8_t* hostOut, size_t outputImage
     const size_t outBytes = dPitch * h, aBytes = hostAlpha ? (size_t)strideA * h : 0, oA = (outBytes + 31) & ~(size_t)15;
     int rc = yk_dec_scratch(c, oA + aBytes + 64); if (rc) return rc;
     if (hostAlpha) YK_HIP(c, hipMemcpyAsync(c->dScratch + oA, hostAlpha, aBytes, hipMemcpyHostToDevice, c->stream));
+    { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_DETILE); if (rc2) return rc2; }
     hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
                        (hostAlpha && !refRGBA) ? c->dScratch + oA : (const uint8_t*)nullptr, strideA, c->dScratch, dPitch);
     YK_HIP(c, hipGetLastError());
+    { int rc2 = yk_stage_end(c, YK_STAGE_DEC_DETILE); if (rc2) return rc2; }
     if (refRGBA && hostAlpha) {
         hipLaunchKernelGGL(yk_dec_ref_alpha_kernel, dim3((h + 255) / 256), dim3(256), 0, c->stream, c->dScratch + oA, strideA, aBytes, w, h, c->dScratch, dPitch);
         YK_HIP(c, hipGetLastError());

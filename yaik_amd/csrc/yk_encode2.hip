@@ -61,30 +61,50 @@ __device__ __forceinline__ y2u2 y2_splat(int v) { const unsigned short t = (unsi
 __device__ __forceinline__ y2s2 y2_splats(int v) { const short t = (short)v; return (y2s2){ t, t }; }
 #define YK2_LATN 85                                                      // 17 x 5 lattice points (every 4th pixel incl. the halo) per strip
 
+// Tile-level decisions as wave-uniform 64-bit lane masks on the scalar unit (lane = macroTile*16 + cellY*4 + cellX): a tile of NX x NY
+// cells is represented by the bit of its origin cell's lane.
+template <int NX, int NY> __device__ __forceinline__ constexpr unsigned long long y2_origin() {      // lanes that are tile origins
+    unsigned long long m = 0;
+    for (int y = 0; y < 4; y += NY) for (int x = 0; x < 4; x += NX) m |= 1ULL << (y * 4 + x);
+    return m * 0x0001000100010001ULL;
+}
+template <int NX, int NY> __device__ __forceinline__ unsigned long long y2_fold(unsigned long long m) {   // origin bit <- OR over the tile's lanes
+    if (NX >= 2) m |= m >> 1;
+    if (NX == 4) m |= m >> 2;
+    if (NY >= 2) m |= m >> 4;
+    if (NY == 4) m |= m >> 8;
+    return m;                                                            // only the origin bits are meaningful
+}
+template <int NX, int NY> __device__ __forceinline__ unsigned long long y2_spread(unsigned long long m) { // origin bits -> all lanes of the tile
+    if (NX >= 2) m |= m << 1;
+    if (NX == 4) m |= m << 2;
+    if (NY >= 2) m |= m << 4;
+    if (NY == 4) m |= m << 8;
+    return m;
+}
+
 template <int SX, int SY>
-__device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy, const int lane,
-                                             const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes,
+__device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy,
+                                             const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes, const bool stripInside,
                                              const int gxCell, const int gyCell, const int w, const int h, const int rf,
                                              uint32_t* s_bm, const int bxCell, const int byCell) {
     constexpr int TX = 1 << SX, TY = 1 << SY, NX = TX / 4, NY = TY / 4;
+    constexpr unsigned long long ORG = y2_origin<NX, NY>();
     const int dcx = cx & (NX - 1), dcy = cy & (NY - 1);                  // this cell's offset inside its tile, in cells
-    const int olane = lane - (dcy * 4 + dcx);                            // lane that owns the tile's origin cell
-    constexpr unsigned long long rowPat = (1ULL << NX) - 1ULL;
-    constexpr unsigned long long P0 = rowPat | (NY >= 2 ? rowPat << 4 : 0ULL) | (NY == 4 ? (rowPat << 8) | (rowPat << 12) : 0ULL);
-    const unsigned long long tm = P0 << olane;                           // lanes (= cells) of this lane's tile
-    const int tgx = gxCell - dcx * 4, tgy = gyCell - dcy * 4;            // tile origin, stripe-local pixels
-    const bool inside = (tgx + TX <= w) && (tgy + TY <= h);
-    const bool allow = inside && (((cov >> olane) & 1ULL) == 0ULL);      // top-left pixel of the tile uncovered (:3871-3875)
-    bool viable = allow && ((deadLanes & tm) == 0ULL);
-    if (__ballot(viable) == 0ULL) return;
+    // viable tiles (origin bits): top-left pixel uncovered (:3871-3875), no cell killed by the curvature test, whole tile inside the image
+    unsigned long long viable = ORG & ~cov & ~y2_fold<NX, NY>(deadLanes);
+    if (!stripInside) {
+        const int tgx = gxCell - dcx * 4, tgy = gyCell - dcy * 4;        // tile origin, stripe-local pixels
+        viable &= __ballot((tgx + TX <= w) && (tgy + TY <= h));
+    }
+    if (viable == 0ULL) return;
 
     // per stream: S (at the current pixel, biased), step along x, and the constants of the walk
     const int lo = lat - dcy * 17 - dcx;                                 // lattice index of the tile origin
     const y2u2 wy2 = y2_splat(16 - ((dcy * 4) << (4 - SY)));             // weight of the cell's first pixel row
     const y2u2 lx2 = y2_splat(16 - ((dcx * 4) << (4 - SX)));             // weight of the cell's first pixel column
     y2u2 S[5], st[5], dS0[5], dS3[5], dst[5];
-#pragma unroll
-    for (int t = 0; t < 5; t++) {
+    auto setup = [&](const int t) {
         const uint32_t* lt = s_lat + t * YK2_LATN + lo;
         const y2u2 TL = y2_u2(lt[0]), TR = y2_u2(lt[NX]), BL = y2_u2(lt[NY * 17]), BR = y2_u2(lt[NY * 17 + NX]);
         // L(r) = 16 BL + (TL-BL) wy, R(r) = 16 BR + (TR-BR) wy, dL = L - R, S'(x0) = 16 R + dL lx0, step = dL * 16/TX, wy(r) = wy0 - r * 16/TY
@@ -95,25 +115,12 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         st[t] = (e16 + f * wy2) << (4 - SX);                             // S'(x, r) - S'(x+1, r)
         dst[t] = f << (8 - SX - SY);                                     // step(r) - step(r+1)
         dS3[t] = dS0[t] - dst[t] * (unsigned short)3;                    // S'(x0+3, r) - S'(x0+3, r+1)
-    }
+    };
     const int loO = -256 * rf, hiO = 256 * rf + 255;
     const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
     y2s2 mn[5], mx[5];
-    unsigned long long bO[3], bR[3];
-    auto variants = [&]() {                                              // lanes failing each of the six variants, so far
-        const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]);   // (raw | Round6) over the channels
-        const y2s2 mxA = __builtin_elementwise_max(__builtin_elementwise_max(mx[0], mx[1]), mx[2]);
-        const y2s2 mnP = __builtin_elementwise_min(mn[3], mn[4]), mxP = __builtin_elementwise_max(mx[3], mx[4]);   // Round6P, either half
-        const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
-        const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
-        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
-        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
-        bO[0] = __ballot(oA.x > 0); bO[1] = __ballot(oA.y > 0); bO[2] = __ballot((oP.x > 0) | (oP.y > 0));
-        bR[0] = __ballot(rA.x > 0); bR[1] = __ballot(rA.y > 0); bR[2] = __ballot((rP.x > 0) | (rP.y > 0));
-    };
-
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
+    // one row of the cell for the streams in `mask`; `first`: these streams' running extremes start with this row's first pixel
+    auto pixelRow = [&](const int r, const unsigned mask, const bool first) {
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             const int i = (r & 1) ? 3 - ii : ii;                         // serpentine: odd rows right to left
@@ -124,34 +131,74 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
             const y2s2 cc[4] = { __builtin_shufflevector(c01, c01, 0, 0), __builtin_shufflevector(c01, c01, 1, 1), c22, c01 };
 #pragma unroll
             for (int t = 0; t < 5; t++) {
+                if (!((mask >> t) & 1u)) continue;
                 const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(S[t]), cc[t == 4 ? 2 : t]);
-                if (r == 0 && ii == 0) { mn[t] = D; mx[t] = D; }             // the first pixel starts the running extremes
+                if (first && ii == 0) { mn[t] = D; mx[t] = D; }
                 else { mn[t] = __builtin_elementwise_min(mn[t], D); mx[t] = __builtin_elementwise_max(mx[t], D); }
                 if (ii < 3) S[t] = (r & 1) ? S[t] + st[t] : S[t] - st[t];
             }
         }
-        if (r < 3) {
+    };
+    auto nextRow = [&](const int r) {                                    // from the end of row r to the start of row r + 1
 #pragma unroll
-            for (int t = 0; t < 5; t++) { S[t] -= (r & 1) ? dS0[t] : dS3[t]; st[t] -= dst[t]; }
-        }
-        if (r == 0) {
-            // after one row: a tile is already lost if each of its six variants has a failing lane; if that holds for every
-            // viable tile of the wave the remaining three rows cannot change any decision.
-            variants();
-            bool lost = true;
+        for (int t = 0; t < 5; t++) { S[t] -= (r & 1) ? dS0[t] : dS3[t]; st[t] -= dst[t]; }
+    };
+    // tiles (origin bits) in which each of the six variants of :3929-3991 already has a failing lane, given the running extremes of
+    // the (raw | Round6) streams merged over their channels (A) and of the Round6P streams (P): such a tile can no longer be accepted
+    auto failAll = [&](const y2s2 mnA, const y2s2 mxA, const y2s2 mnP, const y2s2 mxP) -> unsigned long long {
+        const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
+        const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
+        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
+        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
+        unsigned long long f = y2_fold<NX, NY>(__ballot(oA.x > 0));
+        f &= y2_fold<NX, NY>(__ballot(oA.y > 0));
+        f &= y2_fold<NX, NY>(__ballot((oP.x > 0) | (oP.y > 0)));
+        f &= y2_fold<NX, NY>(__ballot(rA.x > 0));
+        f &= y2_fold<NX, NY>(__ballot(rA.y > 0));
+        f &= y2_fold<NX, NY>(__ballot((rP.x > 0) | (rP.y > 0)));
+        return f;
+    };
+    auto failAllStreams = [&]() -> unsigned long long {
+        return failAll(__builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]),        // (raw | Round6) over the channels
+                       __builtin_elementwise_max(__builtin_elementwise_max(mx[0], mx[1]), mx[2]),
+                       __builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));   // Round6P, either half
+    };
+
+    // Row 0 of every cell first.  Tiles of four or more cells are screened with two of the five streams (channel 0 of the raw and
+    // Round6 corners, channels 0 and 1 of the Round6P corners): on noisy content that already fails every variant of every tile of
+    // the wave, and the other three streams are never set up.  Exact either way: a tile is only dropped when each of its six
+    // variants has a failing pixel, and the remaining streams catch up on row 0 before the next test.
+    constexpr bool kScreen = (NX * NY >= 4);
+    if (kScreen) {
+        setup(0); setup(3);
+        pixelRow(0, 0x09u, true);
+        viable &= ~failAll(mn[0], mx[0], mn[3], mx[3]);
+        if (viable == 0ULL) return;
+        setup(1); setup(2); setup(4);
+        pixelRow(0, 0x16u, true);
+    } else {
 #pragma unroll
-            for (int s = 0; s < 3; s++) lost = lost && ((bO[s] & tm) != 0ULL) && ((bR[s] & tm) != 0ULL);
-            viable = viable && !lost;
-            if (__ballot(viable) == 0ULL) return;
-        }
+        for (int t = 0; t < 5; t++) setup(t);
+        pixelRow(0, 0x1Fu, true);
     }
-    variants();
-    bool anyPass = false;                                                // :3998
-#pragma unroll
-    for (int s = 0; s < 3; s++) anyPass = anyPass || ((bO[s] & tm) == 0ULL) || ((bR[s] & tm) == 0ULL);
-    const bool accept = viable && anyPass;
-    cov |= __ballot(accept);                                             // paint coverage (:4029-4037): bit = lane = cell
-    if (accept && dcx == 0 && dcy == 0) {                                // the origin cell's lane sets the bitmap bit (:4026)
+    // after one row: a tile is already lost if each of its six variants has a failing lane; if that holds for every viable tile of
+    // the wave the remaining three rows cannot change any decision.
+    viable &= ~failAllStreams();
+    if (viable == 0ULL) return;
+    nextRow(0);
+    pixelRow(1, 0x1Fu, false);
+    if (NX * NY == 1) {                                                  // 4x4 tiles: one lane per tile, a second look after half of the tile
+        viable &= ~failAllStreams();
+        if (viable == 0ULL) return;
+    }
+    nextRow(1);
+    pixelRow(2, 0x1Fu, false);
+    nextRow(2);
+    pixelRow(3, 0x1Fu, false);
+    const unsigned long long accept = viable & ~failAllStreams();        // some variant never failed (:3998)
+    if (accept == 0ULL) return;
+    cov |= y2_spread<NX, NY>(accept);                                    // paint coverage (:4029-4037): bit = lane = cell
+    if (__builtin_amdgcn_inverse_ballot_w64(accept)) {                   // the origin cell's lane sets the bitmap bit (:4026)
         const int tbx = bxCell >> SX, tby = byCell >> SY;                // tile coordinates inside the 64x64 block
         int bit;
         if (SX == 4 && SY == 4) bit = 0 + tby * 4 + tbx;
@@ -250,6 +297,8 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     // 16 pixels in registers), so the range quantiser's LUTs reuse the same LDS.
     // LUT layout per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19);
     // 3-bit mode m at [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint, same units).
+    // (Waves that walk 2 or 4 consecutive strips instead of ending after one were measured again with this kernel: the loop costs
+    // ~25 spilled registers and the frame gets 8-25 % slower)
     constexpr int kPixWords = 17 * LS, kLutWords = 16 * YK2_LUTW;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kPixWords > kLutWords ? kPixWords : kLutWords];
     uint32_t* const s_pix = s_mem;
@@ -297,49 +346,57 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 
     YK2_PROBE(0);
     if (lane < 24) s_bm[lane] = 0;
-    s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
-    if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
-    // ---- stage the clamped 65x17 strip (Plane::GetPixelValue clamp, encoder/framework.h:116-121); all loads first ------
+    // ---- stage the clamped 65x17 strip (Plane::GetPixelValue clamp, encoder/framework.h:116-121).  All 18 loads of a lane are
+    // issued before the first use and none sits in a divergent branch (a branch ends in a wait for the loads it holds: the round
+    // trips would run one after the other): addresses are clamped instead, every lane loads, and strips on the image's right edge
+    // patch their replicated columns afterwards under a wave-uniform test.  Addresses are a scalar base (first row of the strip)
+    // plus a 32-bit byte offset per lane.
     {
         const int g4 = (lane & 15) * 4, r0 = lane >> 4;
         const int gx = BX * 64 + g4;
-        const bool inX = gx + 3 < w;
+        const bool inX = gx + 3 < w;                                         // w is a multiple of 8: otherwise gx >= w
+        const int gxc = min(gx, w - 4);
         const int gyS = BY * 64 + wave * 16;
+        const int gyB = min(gyS, P.hAvail - 1);                              // wave-uniform
+        const size_t rowBase = (size_t)gyB * (size_t)P.strideElems;
+        const char* const b0 = reinterpret_cast<const char*>(pl0 + rowBase);
+        const char* const b1 = reinterpret_cast<const char*>(pl1 + rowBase);
+        const char* const b2 = reinterpret_cast<const char*>(pl2 + rowBase);
         int4 R[4], G[4], B[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int gy = min(gyS + r0 + 4 * k, P.hAvail - 1);
-            if (inX) {
-                const size_t off = (size_t)gy * P.strideElems + gx;
-                R[k] = *reinterpret_cast<const int4*>(pl0 + off);
-                G[k] = *reinterpret_cast<const int4*>(pl1 + off);
-                B[k] = *reinterpret_cast<const int4*>(pl2 + off);
-            } else {
-                const size_t off = (size_t)gy * P.strideElems + (w - 1);
-                const int r = pl0[off], gg = pl1[off], b = pl2[off];
-                R[k] = make_int4(r, r, r, r); G[k] = make_int4(gg, gg, gg, gg); B[k] = make_int4(b, b, b, b);
-            }
+            const int rel = min(gyS + r0 + 4 * k, P.hAvail - 1) - gyB;
+            const uint32_t off = (uint32_t)(rel * P.strideElems + gxc) * 4u;
+            R[k] = *reinterpret_cast<const int4*>(b0 + off);
+            G[k] = *reinterpret_cast<const int4*>(b1 + off);
+            B[k] = *reinterpret_cast<const int4*>(b2 + off);
         }
-        int4 Rb = make_int4(0, 0, 0, 0), Gb = Rb, Bb = Rb;
-        if (lane < 16) {
-            const int gy = min(gyS + 16, P.hAvail - 1);
-            if (inX) {
-                const size_t off = (size_t)gy * P.strideElems + gx;
-                Rb = *reinterpret_cast<const int4*>(pl0 + off);
-                Gb = *reinterpret_cast<const int4*>(pl1 + off);
-                Bb = *reinterpret_cast<const int4*>(pl2 + off);
-            } else {
-                const size_t off = (size_t)gy * P.strideElems + (w - 1);
-                const int r = pl0[off], gg = pl1[off], b = pl2[off];
-                Rb = make_int4(r, r, r, r); Gb = make_int4(gg, gg, gg, gg); Bb = make_int4(b, b, b, b);
-            }
+        // bottom halo row: the 16 segments are loaded by lanes 0..15 (the other lanes repeat them: same lines, coalesced)
+        int4 Rb, Gb, Bb;
+        {
+            const int rel = min(gyS + 16, P.hAvail - 1) - gyB;
+            const uint32_t off = (uint32_t)(rel * P.strideElems + gxc) * 4u;
+            Rb = *reinterpret_cast<const int4*>(b0 + off);
+            Gb = *reinterpret_cast<const int4*>(b1 + off);
+            Bb = *reinterpret_cast<const int4*>(b2 + off);
         }
-        uint32_t hcol = 0;
-        const int hr = lane - 32;
-        if (hr >= 0 && hr < 17) {
-            const int gy = min(gyS + hr, P.hAvail - 1), gxh = min(BX * 64 + 64, w - 1);
-            const size_t off = (size_t)gy * P.strideElems + gxh;
-            hcol = (uint32_t)pl0[off] | ((uint32_t)pl1[off] << 8) | ((uint32_t)pl2[off] << 16);
+        // right halo column: 17 samples, lanes 32..48 (the other lanes repeat the first / last one)
+        uint32_t hcol;
+        const int hr = min(max(lane - 32, 0), 16);
+        {
+            const int rel = min(gyS + hr, P.hAvail - 1) - gyB;
+            const uint32_t off = (uint32_t)(rel * P.strideElems + min(BX * 64 + 64, w - 1)) * 4u;
+            hcol = (uint32_t)*reinterpret_cast<const int32_t*>(b0 + off) | ((uint32_t)*reinterpret_cast<const int32_t*>(b1 + off) << 8) |
+                   ((uint32_t)*reinterpret_cast<const int32_t*>(b2 + off) << 16);
+        }
+        if (BX * 64 + 64 > w) {                                              // wave-uniform: lanes beyond the right edge replicate column w - 1
+            if (!inX) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    R[k] = make_int4(R[k].w, R[k].w, R[k].w, R[k].w); G[k] = make_int4(G[k].w, G[k].w, G[k].w, G[k].w); B[k] = make_int4(B[k].w, B[k].w, B[k].w, B[k].w);
+                }
+                Rb = make_int4(Rb.w, Rb.w, Rb.w, Rb.w); Gb = make_int4(Gb.w, Gb.w, Gb.w, Gb.w); Bb = make_int4(Bb.w, Bb.w, Bb.w, Bb.w);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -356,7 +413,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                                        (uint32_t)Rb.w | ((uint32_t)Gb.w << 8) | ((uint32_t)Bb.w << 16));
             *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = o;
         }
-        if (hr >= 0 && hr < 17) s_pix[hr * LS + 64] = hcol;
+        if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
@@ -410,17 +467,18 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 }
         }
         const unsigned long long deadLanes = __ballot(dead);
+        const bool stripInside = (BX * 64 + 64 <= w) && (BY * 64 + wave * 16 + 16 <= h);     // no tile of the strip crosses the image's edge
         if (~deadLanes != 0ULL && !(P.ablate & 2)) {
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
-            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
             if (~(cov | deadLanes) != 0ULL) {
-                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, lane, pw, cov, deadLanes, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
@@ -470,8 +528,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const bool keepMT = (keepP == nullptr) || discard || (mtIn && keepP[mtIdx] != 0);
     const bool tileLive = part && keepMT;
     const int l00 = lane - cyl * 4 - cxl;                                    // lane of the tile's top-left cell
-    const bool v00 = !((cov >> l00) & 1ULL), v10 = !((cov >> (l00 + 1)) & 1ULL), v01 = !((cov >> (l00 + 4)) & 1ULL), v11 = !((cov >> (l00 + 5)) & 1ULL);
-    const bool valid = tileLive && !((cov >> lane) & 1ULL);                  // valid = mipmapMask && !smoothMap (Plane.cpp:527)
+    // uncovered quadrants of the lane's 8x8 tile (top-left, top-right, bottom-left, bottom-right), from the coverage mask on the scalar unit
+    constexpr unsigned long long O22 = y2_origin<2, 2>();
+    const unsigned long long ncov = ~cov;
+    const bool v00 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>(ncov & O22));
+    const bool v10 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 1) & O22));
+    const bool v01 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 4) & O22));
+    const bool v11 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 5) & O22));
+    const bool valid = tileLive && __builtin_amdgcn_inverse_ballot_w64(ncov);   // valid = mipmapMask && !smoothMap (Plane.cpp:527)
     const int nTop = (int)v00 + (int)v10, nBot = (int)v01 + (int)v11;
     const int valueCount = tileLive ? 16 * (nTop + nBot) : 0;
     const int tileIdx = (tgyl >> 3) * P.tilesW + (tgx >> 3);
@@ -512,6 +576,11 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     } else {
         uint32_t* lut = &s_lut[tw][0];
+        // curve constants for buildLut (test-only reconstruction); fetched here, off the path of the strip's pixel loads
+        if (P.wantDst) {
+            s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
+            if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
+        }
 #if YK2_QPOL != 0
         const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.qtab, 0, YK2_QNR * YK2_QROWS * 16, 0x00020000);
 #endif

@@ -194,14 +194,18 @@ int yk_range1d_encode(yk_ctx* c) {
     }
     uint32_t* cT = c->r1Cnt; uint32_t* cP = cT + T8; uint32_t* bT = cP + T8; uint32_t* bP = bT + nb + 16; uint32_t* tot = bP + nb + 16;
     const unsigned nStrips = (unsigned)(((c->fullW + 63) / 64) * ((c->h + 15) / 16));
+    { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
                        c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP);
+    { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
+    { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
     hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
     hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
     hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
     hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
     hipLaunchKernelGGL(yk_range1d_pack_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, cT, cP, bT, bP, tot, T8, c->r1Slots, c->r1Params, c->r1Pix, c->r1Type);
     YK_HIP(c, hipGetLastError());
+    { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
     uint32_t t[2];
     YK_HIP(c, hipMemcpyAsync(t, tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));

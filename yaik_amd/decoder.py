@@ -71,6 +71,15 @@ class HipTileDecoder:
         _chk(self._h, fn(self._h, out.ctypes.data, stride, a.ctypes.data if a is not None else None, a.shape[1] if a is not None else 0))
         return out
 
+    def image_into(self, out: np.ndarray) -> None:
+        """RGB rows into a caller-owned [h, stride] uint8 array (no allocation per call)."""
+        _chk(self._h, lib().yk_decode_output(self._h, out.ctypes.data, out.shape[1], None, 0))
+
+    def stage_ms(self, stage: int) -> tuple[float, int]:
+        ms, n = C.c_float(), C.c_int()
+        _chk(self._h, lib().yk_stage_ms(self._h, stage, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def tile4x4(self) -> np.ndarray:
         n = ((((self.w + 15) >> 4) << 2) * (((self.h + 7) >> 3) << 1)) >> 3
         out = np.zeros(n, dtype=np.uint8)

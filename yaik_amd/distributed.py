@@ -14,13 +14,25 @@ import numpy as np
 
 
 def stripe_rows(full_h: int, world: int, rank: int) -> tuple[int, int, int]:
-    """(y0, h, halo_rows) of rank's stripe: heights are multiples of 64, the last rank takes the remainder."""
+    """(y0, h, halo_rows) of rank's stripe.  The image's 64-row blocks are dealt as evenly as possible (floor + remainder), so every
+    rank owns at least one block whenever there are at least `world` of them; stripe heights are multiples of 64 except the last
+    one.  With fewer blocks than ranks the trailing ranks get h == 0: they skip the encode but must still join the bounding-box
+    combine (with the empty box) and the gather (with an empty payload), see `stripe_is_empty`."""
     blocks = (full_h + 63) // 64
-    per = (blocks + world - 1) // world
-    y0 = min(rank * per * 64, full_h)
-    y1 = min((rank + 1) * per * 64, full_h)
+    base, rem = divmod(blocks, world)
+    start = rank * base + min(rank, rem)
+    count = base + (1 if rank < rem else 0)
+    y0 = min(start * 64, full_h)
+    y1 = min((start + count) * 64, full_h)
     halo = 1 if y1 < full_h and y1 > y0 else 0
     return y0, y1 - y0, halo
+
+
+EMPTY_BBOX = (9999999, 9999999, -1, -1)
+
+
+def stripe_is_empty(full_h: int, world: int, rank: int) -> bool:
+    return stripe_rows(full_h, world, rank)[1] == 0
 
 
 def combine_bboxes(boxes: np.ndarray) -> np.ndarray:

@@ -208,6 +208,16 @@ class HipTileEncoder:
                                             typ.ctypes.data if typ.size else None, typ.size, None))
         return pix, typ
 
+    def gradient_corners_run(self) -> None:
+        """Builds the seven corner streams on the device (no copy to the host)."""
+        _chk(self._h, lib().yk_gradient_corners_run(self._h))
+
+    def stage_ms(self, stage: int) -> tuple[float, int]:
+        """(sum of the event-timed kernel intervals of a YK_STAGE_* since the last query, number of intervals)."""
+        ms, n = C.c_float(), C.c_int()
+        _chk(self._h, lib().yk_stage_ms(self._h, stage, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def export_capacity(self) -> int:
         return int(lib().yk_export_capacity(self._h))
 

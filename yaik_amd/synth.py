@@ -66,34 +66,37 @@ def synth_planes(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12
     return np.ascontiguousarray(np.stack(planes).astype(np.int32))
 
 
-def synth_planes_torch(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12345, device="cuda"):
-    """Same image as synth_planes, generated on `device` with torch (int32 tensor [n, h, w]).
-    The LCG is evaluated in closed form per pixel (affine-map power by squaring, mod 2^32)."""
+def synth_planes_torch(w: int, h: int | None = None, n_planes: int = 4, seed: int = 12345, device="cuda", row0: int = 0, rows: int | None = None):
+    """Same image as synth_planes, generated on `device` with torch (int32 tensor [n, rows, w]).
+    The LCG is evaluated in closed form per pixel (affine-map power by squaring, mod 2^32), so any band of rows
+    [row0, row0 + rows) of the w x h image can be generated on its own (row stripes of one large image)."""
     import torch
     if h is None:
         h = w
+    if rows is None:
+        rows = h - row0
     W = w
-    n = w * h
+    n = w * rows
     M = 0xFFFFFFFF
-    k = torch.arange(1, n + 1, dtype=torch.int64, device=device)          # pixel i uses LCG^(i+1)(seed)
+    k = torch.arange(1, n + 1, dtype=torch.int64, device=device) + row0 * w          # pixel i uses LCG^(i+1)(seed)
     A = torch.ones(n, dtype=torch.int64, device=device)
     Cc = torch.zeros(n, dtype=torch.int64, device=device)
     pa, pc = _A, _C
-    for bit in range(max(1, int(n).bit_length())):
+    for bit in range(max(1, int(w * h).bit_length())):
         sel = ((k >> bit) & 1).bool()
         A = torch.where(sel, (A * pa) & M, A)
         Cc = torch.where(sel, (Cc * pa + pc) & M, Cc)
         pc = (pa * pc + pc) & M
         pa = (pa * pa) & M
-    s = ((A * (seed & M) + Cc) & M).reshape(h, w)
+    s = ((A * (seed & M) + Cc) & M).reshape(rows, w)
     del A, Cc, k
-    y = torch.arange(h, dtype=torch.int64, device=device).reshape(h, 1).expand(h, w)
-    x = torch.arange(w, dtype=torch.int64, device=device).reshape(1, w).expand(h, w)
+    y = torch.arange(row0, row0 + rows, dtype=torch.int64, device=device).reshape(rows, 1).expand(rows, w)
+    x = torch.arange(w, dtype=torch.int64, device=device).reshape(1, w).expand(rows, w)
     kk = ((x >> 6) + (y >> 6)) & 3
     base = [(255 * x) // W, torch.clamp((255 * y) // W, max=255), torch.clamp((255 * (x + y)) // (2 * W), max=255)]
     n2 = [(s >> 8) & 7, (s >> 12) & 7, (s >> 16) & 7]
     n3 = [(s >> 8) & 255, (s >> 16) & 255, (s >> 24) & 255]
-    out = torch.empty((n_planes, h, w), dtype=torch.int32, device=device)
+    out = torch.empty((n_planes, rows, w), dtype=torch.int32, device=device)
     for c in range(3):
         v = torch.where(kk == 2, (base[c] + n2[c]) % 256, base[c])
         v = torch.where(kk == 3, n3[c], v)
