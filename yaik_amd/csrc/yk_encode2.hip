@@ -87,7 +87,7 @@ template <int SX, int SY>
 __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy,
                                              const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes, const bool stripInside,
                                              const int gxCell, const int gyCell, const int w, const int h, const int rf,
-                                             uint32_t* s_bm, const int bxCell, const int byCell) {
+                                             uint32_t* s_bm, const int bxCell, const int byCell, const uint32_t* s_pix, uint8_t* s_list, const int lane) {
     constexpr int TX = 1 << SX, TY = 1 << SY, NX = TX / 4, NY = TY / 4;
     constexpr unsigned long long ORG = y2_origin<NX, NY>();
     const int dcx = cx & (NX - 1), dcy = cy & (NY - 1);                  // this cell's offset inside its tile, in cells
@@ -98,6 +98,93 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         viable &= __ballot((tgx + TX <= w) && (tgy + TY <= h));
     }
     if (viable == 0ULL) return;
+    const int loO = -256 * rf, hiO = 256 * rf + 255;
+    const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
+
+#ifndef YK2_NO_COMPACT
+    // ---- few viable cells (a strip whose larger tiles failed along an edge, the usual case next to contours): a pass over 64 lanes
+    // would keep at most a quarter of them busy for four rows.  Instead lane (j, r) = (j-th viable cell, row r of it) evaluates ONE row
+    // of a viable cell, all five streams; the pixels come from the staged strip in LDS.  Decisions go back to the cells' own lanes
+    // through ballots, so everything after the evaluation is the same as in the full pass.
+    const unsigned long long cells = y2_spread<NX, NY>(viable);
+    const int nCells = __popcll(cells);
+    if (nCells <= 16) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cells >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cells, 0u));
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(cells);
+        if (mine) s_list[rank] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int j = lane & 15, r = lane >> 4;
+        const bool act = j < nCells;
+        const int c = (int)s_list[act ? j : 0];
+        const int q2 = c >> 4, cy2 = (c >> 2) & 3, cx2 = c & 3;
+        const int dcx2 = cx2 & (NX - 1), dcy2 = cy2 & (NY - 1);
+        const int lo2 = cy2 * 17 + q2 * 4 + cx2 - dcy2 * 17 - dcx2;          // lattice index of the tile origin
+        const y2u2 wyr = y2_splat(16 - ((dcy2 * 4 + r) << (4 - SY)));       // weight of row r of the cell
+        const y2u2 lxc = y2_splat(16 - ((dcx2 * 4) << (4 - SX)));           // weight of the cell's first pixel column
+        const uint4 pr = *reinterpret_cast<const uint4*>(&s_pix[(cy2 * 4 + r) * LS + q2 * 16 + cx2 * 4]);
+        const uint32_t px[4] = { pr.x ^ 0x00808080u, pr.y ^ 0x00808080u, pr.z ^ 0x00808080u, pr.w ^ 0x00808080u };   // bias of the packed arithmetic
+        y2u2 Sc[5], stc[5];
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const uint32_t* lt = s_lat + t * YK2_LATN + lo2;
+            const y2u2 TL = y2_u2(lt[0]), TR = y2_u2(lt[NX]), BL = y2_u2(lt[NY * 17]), BR = y2_u2(lt[NY * 17 + NX]);
+            const y2u2 e16 = (BL - BR) << 4, g = TR - BR, f = TL - BL - g;
+            const y2u2 c2 = (g << 4) + f * lxc;
+            Sc[t] = ((BR << 8) + e16 * lxc + c2 * wyr) ^ y2_splat(0x8000);   // S'(x0, row r), biased
+            stc[t] = (e16 + f * wyr) << (4 - SX);                            // S'(x, r) - S'(x+1, r)
+        }
+        y2s2 mnc[5], mxc[5];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p = px[i];
+            const y2s2 c01 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))), c22 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu)));
+            const y2s2 cc[4] = { __builtin_shufflevector(c01, c01, 0, 0), __builtin_shufflevector(c01, c01, 1, 1), c22, c01 };
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(Sc[t]), cc[t == 4 ? 2 : t]);
+                if (i == 0) { mnc[t] = D; mxc[t] = D; }
+                else { mnc[t] = __builtin_elementwise_min(mnc[t], D); mxc[t] = __builtin_elementwise_max(mxc[t], D); }
+                if (i < 3) Sc[t] = Sc[t] - stc[t];
+            }
+        }
+        const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mnc[0], mnc[1]), mnc[2]), mxA = __builtin_elementwise_max(__builtin_elementwise_max(mxc[0], mxc[1]), mxc[2]);
+        const y2s2 mnP = __builtin_elementwise_min(mnc[3], mnc[4]), mxP = __builtin_elementwise_max(mxc[3], mxc[4]);
+        const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
+        const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
+        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
+        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
+        // failing (cell, row) lanes per variant -> OR over the four rows (bits 16 r + j -> bit j) -> back to the cells' own lanes by their rank
+        auto toCells = [&](const bool fail) -> unsigned long long {
+            unsigned long long b = __ballot(fail && act);
+            b |= b >> 16; b |= b >> 32;
+            const uint32_t e = (uint32_t)b & 0xFFFFu;
+            return __ballot(mine && ((e >> rank) & 1u));
+        };
+        unsigned long long f = y2_fold<NX, NY>(toCells(oA.x > 0));
+        f &= y2_fold<NX, NY>(toCells(oA.y > 0));
+        f &= y2_fold<NX, NY>(toCells(rA.x > 0));
+        f &= y2_fold<NX, NY>(toCells(rA.y > 0));
+        f &= y2_fold<NX, NY>(toCells((oP.x > 0) | (oP.y > 0)));
+        f &= y2_fold<NX, NY>(toCells((rP.x > 0) | (rP.y > 0)));
+        const unsigned long long acceptC = viable & ~f;                      // some variant never failed (:3998)
+        if (acceptC != 0ULL) {
+            cov |= y2_spread<NX, NY>(acceptC);
+            if (__builtin_amdgcn_inverse_ballot_w64(acceptC)) {
+                const int tbx = bxCell >> SX, tby = byCell >> SY;
+                int bit;
+                if (SX == 4 && SY == 4) bit = 0 + tby * 4 + tbx;
+                else if (SX == 4 && SY == 3) bit = 32 + tby * 4 + tbx;
+                else if (SX == 3 && SY == 4) bit = 64 + tby * 8 + tbx;
+                else if (SX == 3 && SY == 3) bit = 96 + tby * 8 + tbx;
+                else if (SX == 3 && SY == 2) bit = 160 + (tby >> 3) * 64 + (tby & 7) * 8 + tbx;
+                else if (SX == 2 && SY == 3) bit = 288 + (tbx >> 3) * 64 + tby * 8 + (tbx & 7);
+                else bit = 416 + ((tby >> 3) * 2 + (tbx >> 3)) * 64 + (tby & 7) * 8 + (tbx & 7);
+                atomicOr(&s_bm[bit >> 5], 1u << (bit & 31));
+            }
+        }
+        return;
+    }
+#endif
 
     // per stream: S (at the current pixel, biased), step along x, and the constants of the walk
     const int lo = lat - dcy * 17 - dcx;                                 // lattice index of the tile origin
@@ -116,8 +203,6 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         dst[t] = f << (8 - SX - SY);                                     // step(r) - step(r+1)
         dS3[t] = dS0[t] - dst[t] * (unsigned short)3;                    // S'(x0+3, r) - S'(x0+3, r+1)
     };
-    const int loO = -256 * rf, hiO = 256 * rf + 255;
-    const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
     y2s2 mn[5], mx[5];
     // one row of the cell for the streams in `mask`; `first`: these streams' running extremes start with this row's first pixel
     auto pixelRow = [&](const int r, const unsigned mask, const bool first) {
@@ -139,63 +224,86 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
             }
         }
     };
-    auto nextRow = [&](const int r) {                                    // from the end of row r to the start of row r + 1
+    auto nextRow = [&](const int r, const unsigned mask) {               // from the end of row r to the start of row r + 1, streams in `mask`
 #pragma unroll
-        for (int t = 0; t < 5; t++) { S[t] -= (r & 1) ? dS0[t] : dS3[t]; st[t] -= dst[t]; }
+        for (int t = 0; t < 5; t++) if ((mask >> t) & 1u) { S[t] -= (r & 1) ? dS0[t] : dS3[t]; st[t] -= dst[t]; }
     };
-    // tiles (origin bits) in which each of the six variants of :3929-3991 already has a failing lane, given the running extremes of
-    // the (raw | Round6) streams merged over their channels (A) and of the Round6P streams (P): such a tile can no longer be accepted
-    auto failAll = [&](const y2s2 mnA, const y2s2 mxA, const y2s2 mnP, const y2s2 mxP) -> unsigned long long {
+    // Lanes failing a variant -> tiles (origin bits) with a failing lane.  The six variants of :3929-3991 are range tests on the running
+    // extremes: A = the (raw | Round6) streams merged over their channels, halves x / y = raw / Round6 corners; P = the Round6P streams
+    // (either half); O / R = the window without / with the rounding term.
+    auto failA4 = [&](const y2s2 mnA, const y2s2 mxA) -> unsigned long long {      // tiles in which raw-O, raw-R, Round6-O and Round6-R all have a failing lane
         const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
         const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
-        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
-        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
         unsigned long long f = y2_fold<NX, NY>(__ballot(oA.x > 0));
         f &= y2_fold<NX, NY>(__ballot(oA.y > 0));
-        f &= y2_fold<NX, NY>(__ballot((oP.x > 0) | (oP.y > 0)));
         f &= y2_fold<NX, NY>(__ballot(rA.x > 0));
         f &= y2_fold<NX, NY>(__ballot(rA.y > 0));
-        f &= y2_fold<NX, NY>(__ballot((rP.x > 0) | (rP.y > 0)));
         return f;
     };
-    auto failAllStreams = [&]() -> unsigned long long {
-        return failAll(__builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]),        // (raw | Round6) over the channels
-                       __builtin_elementwise_max(__builtin_elementwise_max(mx[0], mx[1]), mx[2]),
-                       __builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));   // Round6P, either half
+    auto failP2 = [&](const y2s2 mnP, const y2s2 mxP) -> unsigned long long {      // tiles in which Round6P-O and Round6P-R both have a failing lane
+        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
+        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
+        return y2_fold<NX, NY>(__ballot((oP.x > 0) | (oP.y > 0))) & y2_fold<NX, NY>(__ballot((rP.x > 0) | (rP.y > 0)));
     };
+    auto mnAll = [&]() { return __builtin_elementwise_min(__builtin_elementwise_min(mn[0], mn[1]), mn[2]); };   // (raw | Round6) over the channels
+    auto mxAll = [&]() { return __builtin_elementwise_max(__builtin_elementwise_max(mx[0], mx[1]), mx[2]); };
 
-    // Row 0 of every cell first.  Tiles of four or more cells are screened with two of the five streams (channel 0 of the raw and
-    // Round6 corners, channels 0 and 1 of the Round6P corners): on noisy content that already fails every variant of every tile of
-    // the wave, and the other three streams are never set up.  Exact either way: a tile is only dropped when each of its six
-    // variants has a failing pixel, and the remaining streams catch up on row 0 before the next test.
+    // Order of evaluation (exact either way: a tile is dropped only when each of its six variants has a failing pixel, and accepted
+    // only when some variant has none over the whole tile):
+    //  * row 0 of every cell first; tiles of four or more cells are screened with two of the five streams (channel 0 of the raw and
+    //    Round6 corners, channels 0 and 1 of the Round6P corners): on noisy content that already fails every variant of every tile
+    //    of the wave, and the other streams are never set up;
+    //  * the (raw | Round6) streams run ahead over the four rows; the Round6P streams only finish for waves that hold a tile none of
+    //    the four raw / Round6 variants accepts (on clean gradients the raw corners pass and two streams in five are never walked).
     constexpr bool kScreen = (NX * NY >= 4);
+    constexpr unsigned kA = 0x07u, kP = 0x18u;
+    int pRows;                                                           // rows the Round6P streams have walked so far
     if (kScreen) {
         setup(0); setup(3);
         pixelRow(0, 0x09u, true);
-        viable &= ~failAll(mn[0], mx[0], mn[3], mx[3]);
+        viable &= ~(failA4(mn[0], mx[0]) & failP2(mn[3], mx[3]));
         if (viable == 0ULL) return;
-        setup(1); setup(2); setup(4);
-        pixelRow(0, 0x16u, true);
+        setup(1); setup(2);
+        pixelRow(0, 0x06u, true);
+        viable &= ~(failA4(mnAll(), mxAll()) & failP2(mn[3], mx[3]));      // after one row: lost tiles cannot be accepted by later rows
+        if (viable == 0ULL) return;
+        nextRow(0, kA);
+        pixelRow(1, kA, false);
+        pRows = 0;                                                       // stream 3 has walked row 0, stream 4 nothing yet
     } else {
 #pragma unroll
         for (int t = 0; t < 5; t++) setup(t);
         pixelRow(0, 0x1Fu, true);
-    }
-    // after one row: a tile is already lost if each of its six variants has a failing lane; if that holds for every viable tile of
-    // the wave the remaining three rows cannot change any decision.
-    viable &= ~failAllStreams();
-    if (viable == 0ULL) return;
-    nextRow(0);
-    pixelRow(1, 0x1Fu, false);
-    if (NX * NY == 1) {                                                  // 4x4 tiles: one lane per tile, a second look after half of the tile
-        viable &= ~failAllStreams();
+        viable &= ~(failA4(mnAll(), mxAll()) & failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4])));
         if (viable == 0ULL) return;
+        nextRow(0, 0x1Fu);
+        pixelRow(1, 0x1Fu, false);
+        if (NX * NY == 1) {                                              // 4x4 tiles: one lane per tile, a second look after half of the tile
+            viable &= ~(failA4(mnAll(), mxAll()) & failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4])));
+            if (viable == 0ULL) return;
+        }
+        pRows = 2;
     }
-    nextRow(1);
-    pixelRow(2, 0x1Fu, false);
-    nextRow(2);
-    pixelRow(3, 0x1Fu, false);
-    const unsigned long long accept = viable & ~failAllStreams();        // some variant never failed (:3998)
+    nextRow(1, kA);
+    pixelRow(2, kA, false);
+    nextRow(2, kA);
+    pixelRow(3, kA, false);
+    unsigned long long accept = viable & ~failA4(mnAll(), mxAll());      // some raw / Round6 variant never failed (:3998)
+    const unsigned long long rest = viable & ~accept;
+    if (rest != 0ULL) {                                                  // wave-uniform: the Round6P variants decide the remaining tiles
+        if (kScreen) {
+            setup(4);
+            pixelRow(0, 0x10u, true);
+            nextRow(0, kP);
+            pixelRow(1, kP, false);
+        }
+        nextRow(1, kP);
+        pixelRow(2, kP, false);
+        nextRow(2, kP);
+        pixelRow(3, kP, false);
+        accept |= rest & ~failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));
+    }
+    (void)pRows;
     if (accept == 0ULL) return;
     cov |= y2_spread<NX, NY>(accept);                                    // paint coverage (:4029-4037): bit = lane = cell
     if (__builtin_amdgcn_inverse_ballot_w64(accept)) {                   // the origin cell's lane sets the bitmap bit (:4026)
@@ -304,6 +412,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     uint32_t* const s_pix = s_mem;
     uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
+    __shared__ uint8_t s_list[64];                                          // gradient passes with few viable cells: their lanes, compacted
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
     __shared__ float s_rcp[256];                                            // RN(1 / pixel value); [0] = 0 (skipped term, :884)
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
@@ -471,14 +580,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         if (~deadLanes != 0ULL && !(P.ablate & 2)) {
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
-            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
             if (~(cov | deadLanes) != 0ULL) {
-                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
-                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell);
+                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
@@ -807,7 +916,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     *reinterpret_cast<uint16_t*>(slot + (pos >> 1)) = (uint16_t)code16;
                     if (P.wantDst) {
                         const uint32_t* lb = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
-                        int32_t* drow = P.dst[p] + (size_t)(gyCell + r) * w + gxCell;
+                        int32_t* drow = P.dst[p] + (uint32_t)((gyCell + r) * w + gxCell);     // 32-bit element offset from a scalar base (w, h <= 32760)
 #pragma unroll
                         for (int i = 0; i < 4; i++) drow[i] = (int32_t)(lb[(code16 >> (4 * i)) & 15u] >> 8);
                     }
