@@ -13,3 +13,15 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-parity > /dev/null 2> $OUT.pmc3.err
 python3 tools/summarize_prof.py $OUT > ${OUT}_summary.json
 cat ${OUT}_summary.json
+# bench.py reports roofline.traffic from this file only while the kernel source it was measured on is the one in the tree
+python3 - "$TAG" "${OUT}_summary.json" <<'PY' > gpurun_out/traffic_$TAG.json
+import hashlib, json, sys
+tag, path = sys.argv[1], sys.argv[2]
+d = json.load(open(path))["yk_encode2_kernel"]
+print(json.dumps({"kernel": "yk_encode2_kernel", "hbm_traffic_bytes": d["hbm_traffic_bytes"], "fetch_bytes_corrected": d["fetch_bytes_corrected"],
+                  "write_bytes_corrected": d["write_bytes_corrected"], "avg_ns_rocprof": d["avg_ns"],
+                  "kernel_source_sha256": hashlib.sha256(open("yaik_amd/csrc/yk_encode2.hip", "rb").read()).hexdigest(),
+                  "workload": "8192x8192 RGBA, bench.py defaults (two frames in flight, fused kernels ordered)",
+                  "source": f"profiles/{tag[:3]}/{tag[3:]}_pmc_and_stats_summary.json (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, KB -> bytes)"}, indent=1))
+PY
+cat gpurun_out/traffic_$TAG.json
