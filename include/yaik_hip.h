@@ -144,6 +144,24 @@ int    yk_gradient_corners_run(yk_ctx* c);
  * yaik_amd/distributed.py::merge_corner_streams.  capElems >= 2 * (w/4 + 1). */
 int    yk_gradient_corner_edges(yk_ctx* c, uint32_t* hostKeys, uint32_t* hostIndex, size_t capElems);
 
+/* ---- a6 with nullable planes: EncoderContext::FittingQuadSmooth(rejectFactor, srcA, srcB, srcC, ..., tileShiftX, tileShiftY) where one or
+ * two of the planes are NULL (EncoderContext.cpp:3710-4363; PlaneBit :3715; the reference's call sites are the six 4x4 passes RB, RG, GB, R,
+ * G, B of Convert(), :9261-9415, all compiled out or under `if (0)`).  planeBit: bit0/1/2 = srcA/srcB/srcC present (7 = a plain RGB pass).
+ * Runs ONE more pass after yk_encode_tiles, on the state the seven RGB passes left (further calls continue from each other):
+ *   - a tile is tried when its top-left pixel is uncovered in every PRESENT plane (:3871-3875); absent planes read 0 and never reject;
+ *   - accepted tiles paint the per-plane coverage of the present planes and the common coverage (smoothMap; :4029-4037), so yk_coverage
+ *     grows and yk_coverage_plane(p) tells what plane p still has to code in the 1-D path - yk_range1d_encode uses the per-plane
+ *     coverage from the first partial pass on, exactly like DynamicTileCompressor(.., mapSmoothTile->GetPlane(p), ..) (:9451-9460);
+ *   - the corner stream holds one byte per PRESENT plane whose mappedRGB[p] has not seen the lattice point (:4001-4021, :4113-4132).
+ * The 2-D tile maps of yk_encode_tiles are not touched (the reference's partial passes precede only the 1-D compressor).
+ * Single images only (nFrames == 1, whole image: y0 == 0).  *tilesAccepted = the function's return value (TileDone).  Synchronises. */
+int    yk_gradient_partial_pass(yk_ctx* c, int rejectFactor, int planeBit, int tileShiftX, int tileShiftY, int* tilesAccepted);
+/* bitmap (swizzled like yk_gradient_bitmap, size :3770-3777) and corner stream of the LAST partial pass */
+int    yk_partial_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
+int    yk_partial_corners(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
+/* mapSmoothTile->GetPlane(plane) != 0 per 4x4 cell, same layout as yk_coverage (equal to it until the first partial pass) */
+int    yk_coverage_plane(yk_ctx* c, int plane, uint16_t* hostOut, size_t capElems);
+
 /* range-quantiser results per plane (valid after yk_encode_tiles) ---------------------------------
  * tileDefs = `streamTileDef` u16 EncodeTileType(type,range,base) of tiles with >= 1 valid pixel, LeftRightOrder
  * (:4419,:4434-4438); nibbles = `streamTileIdx`, low nibble first (:1180-1184), closed to a whole byte (:4525). */
@@ -184,6 +202,14 @@ int yk_decode_begin(yk_ctx* c, int w, int h);
  * bitmap = swizzled tile bitmap, rgb = corner stream AFTER PaletteDecompressor (0..255). Host pointers. */
 int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* bitmap, size_t bitmapBytes,
                        const uint8_t* rgb, size_t rgbBytes);
+/* DecompressGradient4x4 with a plane subset (decoder/YAIK_Gradient.cpp:1208-1226 -> 4x4R / G / RG / B / RB / GB, :1420-2732): planeBit
+ * 1..6 (bit 0 = R, 1 = G, 2 = B; 7 forwards to yk_decode_gradient).  Like YAIK_API.cpp:875-877 the masks are split per plane first
+ * (UpdateTileAndRGBMask).  Only the 4x4 size has partial-plane loops in the reference.  consistentMarks = 0 reproduces what those loops
+ * do to tile4x4Mask, defects included (the R / G / B loops never mark; GB / RB put the B marks at tile4x4Mask + (size >> 1), :1678,
+ * :1924) -- byte-identical state to the reference decoder; 1 marks every present plane's own mask, which is what the ENCODER's
+ * per-plane coverage and therefore the 1-D streams behind such passes assume (with 0 the reference's own Decompress1D runs off them). */
+int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, const uint8_t* bitmap, size_t bitmapBytes,
+                              const uint8_t* rgb, size_t rgbBytes);
 /* Decompress1D x3 planes (decoder/YAIK_3DTile.cpp:24-240) on the '1DTL' streams (type: 3 B/tile, pix: 1 B/pixel) */
 int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes,
                  int compressionRange);
@@ -203,6 +229,8 @@ const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
 int yk_decode_output(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA);
 int yk_decode_output_reference_rgba(yk_ctx* c, uint8_t* hostOut, size_t outputImageStride, const uint8_t* hostAlpha, int strideA);
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
+/* the three planes of tile4x4Mask back to back (planes 1 and 2 are meaningful once a partial-plane pass has split the masks) */
+int yk_decode_tile4x4_planes(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
 /* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
  * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches

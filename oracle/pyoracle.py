@@ -56,6 +56,7 @@ def _load() -> C.CDLL:
     lib.yko_dec_create.argtypes = [C.c_int, C.c_int]
     lib.yko_dec_destroy.argtypes = [vp]
     lib.yko_dec_gradient.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
+    lib.yko_dec_gradient_planes.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
     lib.yko_dec_split_masks.argtypes = [vp]
     lib.yko_dec_1d.argtypes = [vp, C.c_int, vp, ip, vp, ip, C.c_int]
     lib.yko_dec_mask.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -180,6 +181,14 @@ class OracleDecoder:
         return lib().yko_dec_gradient(self._d, sx, sy, bitmap.ctypes.data, bitmap.size,
                                       rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size)
 
+    def gradient_planes(self, plane_bit: int, bitmap: np.ndarray, rgb_dq: np.ndarray, consistent_marks: bool = False) -> int:
+        """DecompressGradient4x4 with planeBit 1..6 (masks must have been split, like the decoder does for such a chunk).
+        consistent_marks=False reproduces the reference's tile4x4Mask marking defects (pinned); True marks every present plane."""
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        rgb_dq = np.ascontiguousarray(rgb_dq, dtype=np.uint8)
+        return lib().yko_dec_gradient_planes(self._d, plane_bit, int(consistent_marks), bitmap.ctypes.data, bitmap.size,
+                                             rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size)
+
     def split_masks(self):
         lib().yko_dec_split_masks(self._d)
 
@@ -196,20 +205,20 @@ class OracleDecoder:
         p = lib().yko_dec_planes(self._d, C.byref(n))
         return _arr(p, n.value * 3).reshape(3, n.value)
 
-    def tile4x4(self) -> np.ndarray:
+    def tile4x4(self, all_planes: bool = False) -> np.ndarray:
         n = C.c_int()
         p = lib().yko_dec_tile4x4(self._d, C.byref(n))
-        return _arr(p, n.value)
+        return _arr(p, n.value * (3 if all_planes else 1))
 
     def map_rgb(self) -> np.ndarray:
         n = C.c_int()
         p = lib().yko_dec_map_rgb(self._d, C.byref(n))
         return _arr(p, n.value)
 
-    def map_rgb_mask(self) -> np.ndarray:
+    def map_rgb_mask(self, all_planes: bool = False) -> np.ndarray:
         n = C.c_int()
         p = lib().yko_dec_map_rgb_mask(self._d, C.byref(n))
-        return _arr(p, n.value)
+        return _arr(p, n.value * (3 if all_planes else 1))
 
 
 def palette_remap(stream: np.ndarray, original_range: int = 250) -> np.ndarray:

@@ -20,7 +20,10 @@
 // running the reference's own PaletteDecompressor on that output, exactly as the decoder does, which
 // yields the de-quantised bytes the gradient decode loops consume.  No reference code is copied or altered.
 //
-// usage: ref_driver <in.bin> <out.blobs>
+// usage: ref_driver <in.bin> <out.blobs> [partial]
+//   partial : after the seven RGB passes also run the six partial-plane 4x4 passes in the order the reference's Convert() lists them
+//             (RB, RG, GB, R, G, B; EncoderContext.cpp:9261-9415, disabled there by `if (0)` / `#if 0`), before the 1-D path, and
+//             decode them with DecompressGradient4x4(planeBit) (blobs pp_*)
 //   in.bin  : int32 w, h, nPlanes, then nPlanes planes of w*h int32 (row-major, values 0..255)
 #define protected public
 #define private public
@@ -95,7 +98,8 @@ static std::string nm(const char* base, int a, int b = -1) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: ref_driver in.bin out.blobs\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: ref_driver in.bin out.blobs [partial]\n"); return 2; }
+    const bool partial = argc > 3 && !strcmp(argv[3], "partial");
     FILE* fi = fopen(argv[1], "rb");
     if (!fi) { perror("in"); return 2; }
     int hdr[3];
@@ -214,6 +218,45 @@ int main(int argc, char** argv) {
 
     blob("stage_seconds", stage, sizeof stage);
 
+    // ---- a6 with nullable planes: the partial-plane 4x4 passes (PlaneBit :3715, per-plane allow :3871-3875, per-plane paint :4031-4034)
+    static const int ppMask[6] = { 5, 3, 6, 1, 2, 4 };                  // RB, RG, GB, R, G, B
+    std::vector<std::vector<u8>> ppBitmaps(6), ppRgbdq(6);
+    int ppCounts[6] = { 0, 0, 0, 0, 0, 0 };
+    if (partial) {
+        for (int i = 0; i < 6; i++) {
+            gZstd.clear();
+            fflush(ctx->outFile);
+            long before = ftell(ctx->outFile);
+            const int m = ppMask[i];
+            ppCounts[i] = ctx->FittingQuadSmooth(3, (m & 1) ? img->GetPlane(0) : NULL, (m & 2) ? img->GetPlane(1) : NULL, (m & 4) ? img->GetPlane(2) : NULL,
+                                                 preview, false, 2, 2);
+            if (!gZstd.empty()) ppBitmaps[i] = gZstd[0].data;
+            else ppBitmaps[i].assign((((w + 31) / 32) * ((h + 31) / 32) * 64) >> 3, 0);
+            if (gZstd.size() >= 2) {
+                fflush(ctx->outFile);
+                long after = ftell(ctx->outFile);
+                fseek(ctx->outFile, before, SEEK_SET);
+                HeaderBase hb; HeaderGradientTile hg;
+                if (fread(&hb, sizeof hb, 1, ctx->outFile) != 1 || fread(&hg, sizeof hg, 1, ctx->outFile) != 1) return 2;
+                fseek(ctx->outFile, after, SEEK_SET);
+                std::vector<u8> pal(gZstd[1].data); size_t palSize = pal.size(); pal.resize(palSize + 128 * 3, 0);
+                // the palette codec works in RGB triples: with one or two planes the stream length need not be a multiple of 3 and the
+                // reference then writes up to 2 bytes past `outputSize` (YAIK_GenericFunctions.cpp:131-137, :171) - give it the room
+                ppRgbdq[i].assign(hg.streamRGBSizeUncompressed + 4, 0);
+                if (!PaletteDecompressor(pal.data(), (int)palSize, (int)palSize + 128 * 3, ppRgbdq[i].data(), (int)hg.streamRGBSizeUncompressed, hg.colorCompression)) return 3;
+                ppRgbdq[i].resize(hg.streamRGBSizeUncompressed);
+                int hdr2[2] = { (int)hg.plane, (int)hg.format };
+                blob(nm("pp_header", i), hdr2, sizeof hdr2);
+                blob(nm("pp_palette", i), gZstd[1].data.data(), gZstd[1].data.size());
+            }
+            blob(nm("pp_bitmap", i), ppBitmaps[i].data(), ppBitmaps[i].size());
+            blob(nm("pp_rgbdq", i), ppRgbdq[i].data(), ppRgbdq[i].size());
+        }
+        blob("pp_counts", ppCounts, sizeof ppCounts);
+        blobPlane8("pp_smoothMap", ctx->smoothMap);
+        for (int p = 0; p < 3; p++) blobPlane8(nm("pp_mapSmoothTile", p), ctx->mapSmoothTile->GetPlane(p));
+    }
+
     // ---- a15 live 1-D range path ----
     size_t cap = (size_t)w * h * 3 + 64;
     std::vector<u8> pix(cap), types((size_t)(w / 8) * (h / 8) * 9 + 64);
@@ -281,6 +324,17 @@ int main(int argc, char** argv) {
         memcpy(&t4[(size_t)inst.tile4x4MaskSize * p], t4.data(), inst.tile4x4MaskSize);
     }
     inst.singleRGB = false;
+    if (partial) {                                                      // 'GTIL' chunks with plane != 7 come behind the split (YAIK_API.cpp:875-877)
+        for (int i = 0; i < 6; i++) {
+            if (ppCounts[i] == 0) continue;
+            std::vector<u8> rgb(ppRgbdq[i]); rgb.resize(rgb.size() + slack, 0);
+            std::vector<u8> bm(ppBitmaps[i]);
+            DecompressGradient4x4(&inst, bm.data(), rgb.data(), inst.planeR, inst.planeG, inst.planeB, (u8)ppMask[i]);
+        }
+        blob("pp_dec_planes_grad", planes.data(), planes.size());
+        blob("pp_dec_tile4x4", t4.data(), t4.size());
+        blob("pp_dec_mapRGBMask", mapMask.data(), mapMask.size());
+    }
     Header1D h1; memset(&h1, 0, sizeof h1);
     h1.compressionColor = (u8)ctx->colorCompression1D; h1.compressionRange = (u8)ctx->rangeCompression1D;
     std::vector<u8> pixPad(pix.begin(), pix.begin() + ends[2]); pixPad.resize(pixPad.size() + 64, 0);

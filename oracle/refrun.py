@@ -31,7 +31,7 @@ def parse_blobs(path: str) -> dict[str, bytes]:
     return out
 
 
-def run_reference(planes: np.ndarray) -> dict[str, bytes]:
+def run_reference(planes: np.ndarray, partial: bool = False) -> dict[str, bytes]:
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     n, h, w = planes.shape
     with tempfile.TemporaryDirectory() as d:
@@ -40,5 +40,5 @@ def run_reference(planes: np.ndarray) -> dict[str, bytes]:
         with open(fin, "wb") as f:
             f.write(struct.pack("<3i", w, h, n))
             f.write(planes.tobytes())
-        subprocess.run([REF_DRIVER, fin, fout], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([REF_DRIVER, fin, fout] + (["partial"] if partial else []), check=True, stdout=subprocess.DEVNULL)
         return parse_blobs(fout)

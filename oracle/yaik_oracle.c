@@ -647,6 +647,7 @@ struct yko_dec {
     uint8_t* mapRGB;        /* lattice*3 */
     uint8_t* mapRGBMask; int sizeMapMask;
     uint8_t* tile4x4Mask; int tile4x4MaskSize, stride4;
+    int singleRGB;          /* masks still in single-plane form (YAIK_Instance::singleRGB) */
 };
 
 yko_dec* yko_dec_create(int w, int h) {
@@ -662,6 +663,7 @@ yko_dec* yko_dec_create(int w, int h) {
     d->stride4 = (w + 15) >> 4;
     d->tile4x4MaskSize = ((d->stride4 << 2) * (((h + 7) >> 3) << 1)) >> 3;
     d->tile4x4Mask = (uint8_t*)calloc((size_t)d->tile4x4MaskSize * 3, 1);
+    d->singleRGB = 1;
     return d;
 }
 void yko_dec_destroy(yko_dec* d) {
@@ -718,7 +720,70 @@ int yko_dec_gradient(yko_dec* d, int sx, int sy, const uint8_t* bitmap, int bitm
     return rd;
 }
 
+/* a16, partial planes: DecompressGradient4x4R / G / B / RG / GB / RB (decoder/YAIK_Gradient.cpp:1208-1226 dispatch, bodies :1420-2732).
+ * Same walk as the RGB 4x4 loop; per set bit and per corner TL,TR,BL,BR one byte is popped for every PRESENT plane whose own
+ * mapRGBMask plane does not have the lattice point yet (e.g. :1516-1580), only the present planes are filled and only their
+ * tile4x4Mask planes are marked (:1609-1612; with the reference's defects unless consistentMarks, see below).  The masks must be
+ * in per-plane form (UpdateTileAndRGBMask, YAIK_API.cpp:875-877).
+ * planeBit 7 = yko_dec_gradient.  Only the 4x4 size has partial-plane decoders in the reference. */
+int yko_dec_gradient_planes(yko_dec* d, int planeBit, int consistentMarks, const uint8_t* bitmap, int bitmapBytes, const uint8_t* rgb, int rgbBytes) {
+    if (planeBit == 7) return yko_dec_gradient(d, 2, 2, bitmap, bitmapBytes, rgb, rgbBytes);
+    if (planeBit < 1 || planeBit > 6) return -1;
+    const int w = d->w, h = d->h, bigX = 32, bigY = 32, bitCount = 64, TX = 4, TY = 4;
+    int xBB = (w + bigX - 1) / bigX, yBB = (h + bigY - 1) / bigY;
+    if (((xBB * yBB * bitCount) >> 3) > bitmapBytes) return -2;
+    int rd = 0;
+    for (int by = 0; by < yBB; by++) for (int bx = 0; bx < xBB; bx++) {
+        int posBlock = (by * xBB + bx) * bitCount;
+        for (int t = 0; t < bitCount; t++) {
+            int pos = posBlock + t;
+            if (!(bitmap[pos >> 3] & (1 << (pos & 7)))) continue;
+            int x = bx * bigX + (t % 8) * TX, y = by * bigY + (t / 8) * TY;
+            if (x >= w || y >= h) continue;
+            int li[4];
+            li[0] = (x >> 2) + (y >> 2) * d->strideRGBMap;  li[1] = li[0] + 1;
+            li[2] = li[0] + d->strideRGBMap;                li[3] = li[2] + 1;
+            for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) {
+                if (!(planeBit & (1 << c))) continue;
+                uint8_t* has = d->mapRGBMask + (size_t)d->sizeMapMask * c;
+                if (!(has[li[k] >> 3] & (1 << (li[k] & 7)))) {
+                    has[li[k] >> 3] |= (uint8_t)(1 << (li[k] & 7));
+                    d->mapRGB[li[k] * 3 + c] = (rd < rgbBytes) ? rgb[rd] : 0; rd++;
+                }
+            }
+            for (int c = 0; c < 3; c++) {
+                if (!(planeBit & (1 << c))) continue;
+                int TL = d->mapRGB[li[0] * 3 + c], TR = d->mapRGB[li[1] * 3 + c];
+                int BL = d->mapRGB[li[2] * 3 + c], BR = d->mapRGB[li[3] * 3 + c];
+                uint8_t* pl = d->planes + (size_t)c * d->planeSize;
+                for (int ty = 0; ty < TY; ty++) {
+                    int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
+                    for (int tx = 0; tx < TX; tx++) {
+                        int xx = x + tx, yy = y + ty;
+                        pl[(((yy >> 3) * d->tileW) + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7)] = (uint8_t)((L * (TX - tx) + R * tx) >> 4);
+                    }
+                }
+                /* tile4x4Mask marking.  consistentMarks: the plane's own mask, which is what the encoder's per-plane coverage and
+                 * Decompress1D assume.  Otherwise AS THE REFERENCE DOES IT: only the two-plane variants mark at all (the R / G / B loops
+                 * :2138-2732 never touch tile4x4Mask), and GB / RB put the B marks at tile4x4Mask + (tile4x4MaskSize >> 1), i.e. inside
+                 * plane 0 of the mask, instead of + (tile4x4MaskSize << 1) (:1678, :1924). */
+                int cxx = x >> 2, cy = y >> 2;
+                size_t base;
+                if (consistentMarks) base = (size_t)d->tile4x4MaskSize * c;
+                else {
+                    if (planeBit == 1 || planeBit == 2 || planeBit == 4) continue;
+                    base = (c == 2) ? (size_t)(d->tile4x4MaskSize >> 1) : (size_t)d->tile4x4MaskSize * c;
+                }
+                d->tile4x4Mask[base + (cxx >> 2) + (cy >> 1) * d->stride4] |= (uint8_t)(1 << ((((cxx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cxx & 1)));
+            }
+        }
+    }
+    return rd;
+}
+
 void yko_dec_split_masks(yko_dec* d) {
+    if (!d->singleRGB) return;                                             /* once (YAIK_API.cpp:533-534) */
+    d->singleRGB = 0;
     for (int p = 1; p < 3; p++) {
         memcpy(d->mapRGBMask + (size_t)d->sizeMapMask * p, d->mapRGBMask, (size_t)d->sizeMapMask);
         memcpy(d->tile4x4Mask + (size_t)d->tile4x4MaskSize * p, d->tile4x4Mask, (size_t)d->tile4x4MaskSize);

@@ -88,6 +88,12 @@ void     yko_dec_destroy(yko_dec* d);
 /* DecompressGradient{16x16,16x8,8x16,8x8,8x4,4x8,4x4} (decoder/YAIK_Gradient.cpp:28-1418), RGB (planeBit 7).
  * rgb = de-quantised corner stream (after PaletteFullRangeRemapping). Returns bytes of rgb consumed. */
 int yko_dec_gradient(yko_dec* d, int tileShiftX, int tileShiftY, const uint8_t* bitmap, int bitmapBytes, const uint8_t* rgb, int rgbBytes);
+/* DecompressGradient4x4 with planeBit 1..6 (R, G, RG, B, RB, GB; decoder/YAIK_Gradient.cpp:1208-1226, :1420-2732); the masks must have
+ * been split (yko_dec_split_masks) as YAIK_API.cpp:875-877 does for every 'GTIL' chunk whose plane field is not 7.
+ * consistentMarks = 0 reproduces the reference's tile4x4Mask marking of these loops, defects included (no marks from R / G / B,
+ * B marks of GB / RB at a wrong offset): that is what the pinned vectors hold; 1 marks each present plane's own mask, which is what
+ * the ENCODER's per-plane coverage (and therefore Decompress1D behind it) assumes. */
+int yko_dec_gradient_planes(yko_dec* d, int planeBit, int consistentMarks, const uint8_t* bitmap, int bitmapBytes, const uint8_t* rgb, int rgbBytes);
 /* UpdateTileAndRGBMask (decoder/YAIK_API.cpp:530-544) */
 void yko_dec_split_masks(yko_dec* d);
 /* Decompress1D (decoder/YAIK_3DTile.cpp:24-240) for one plane; advances the two cursors. */

@@ -83,6 +83,77 @@ def oracle_blobs(planes: np.ndarray) -> dict:
     return out
 
 
+PP_MASKS = (5, 3, 6, 1, 2, 4)          # RB, RG, GB, R, G, B: the order of Convert()'s (disabled) 4x4 passes, EncoderContext.cpp:9261-9415
+PP_KEEP = ("pp_", "d1_pix", "d1_type", "d1_ends")
+
+
+def oracle_partial_blobs(planes: np.ndarray) -> dict:
+    """The blobs of `ref_driver <in> <out> partial`: the seven RGB passes, then the six partial-plane 4x4 passes, then the 1-D compressor
+    on the per-plane coverage, then DecompressGradient4x4(planeBit) as the reference executes it (consistentMarks = 0)."""
+    n, h, w = planes.shape
+    out = {}
+    enc = OracleEncoder(planes)
+    if n == 4:
+        enc.mip_prefilter()
+    streams = []
+    for sx, sy in PASSES:
+        cnt, bm, rgb = enc.fitting_quad_smooth(sx, sy)
+        dq = palette_decompress(enc.palette_compress(rgb), rgb.size, 250) if cnt else np.zeros(0, np.uint8)
+        streams.append((sx, sy, cnt, bm, dq))
+    pp, counts = [], []
+    for i, m in enumerate(PP_MASKS):
+        cnt, bm, rgb = enc.fitting_quad_smooth(2, 2, plane_bit=m)
+        counts.append(cnt)
+        out[f"pp_bitmap_{i}"] = bm.tobytes()
+        out[f"_pp_rgb_{i}"] = rgb.tobytes()
+        if cnt:
+            pal = enc.palette_compress(rgb)
+            dq = palette_decompress(pal, rgb.size, 250)
+            out[f"pp_palette_{i}"] = pal.tobytes()
+            out[f"pp_header_{i}"] = np.array([m, (2 << 3) | 2], dtype=np.int32).tobytes()
+        else:
+            dq = np.zeros(0, np.uint8)
+        out[f"pp_rgbdq_{i}"] = dq.tobytes()
+        pp.append((m, cnt, bm, dq))
+    out["pp_counts"] = np.array(counts, dtype=np.int32).tobytes()
+    out["pp_smoothMap"] = enc.state("smoothMap").tobytes()
+    for p in range(3):
+        out[f"pp_mapSmoothTile_{p}"] = enc.state("mapSmoothTile", p).tobytes()
+    ends = []
+    for p in range(3):
+        enc.dynamic_tile_compressor(p)
+        pix, typ = enc.streams_1d()
+        ends.append((pix.size, typ.size))
+    out["d1_pix"] = pix.tobytes()
+    out["d1_type"] = typ.tobytes()
+    out["d1_ends"] = np.array([e[0] for e in ends] + [e[1] for e in ends], dtype=np.int32).tobytes()
+    if w % 16 == 0 and h % 16 == 0:
+        dec = OracleDecoder(w, h)
+        for sx, sy, cnt, bm, dq in streams:
+            if cnt:
+                dec.gradient(sx, sy, bm, dq)
+        dec.split_masks()
+        for m, cnt, bm, dq in pp:
+            if cnt:
+                dec.gradient_planes(m, bm, dq, consistent_marks=False)
+        out["pp_dec_planes_grad"] = dec.planes().tobytes()
+        out["pp_dec_tile4x4"] = dec.tile4x4(True).tobytes()
+        out["pp_dec_mapRGBMask"] = dec.map_rgb_mask(True).tobytes()
+    return out
+
+
+def compare_partial(ref: dict, ours: dict) -> list:
+    bad = []
+    for k, v in ref.items():
+        if not k.startswith(PP_KEEP):
+            continue
+        if k not in ours:
+            bad.append(f"missing {k}")
+        elif bytes(v) != ours[k]:
+            bad.append(f"{k}: {len(v)} vs {len(ours[k])} bytes")
+    return bad
+
+
 def parse_mip_chunk(chunk: bytes):
     """'MIPM' chunk as written by MipPrefilter (EncoderContext.cpp:1367-1396): HeaderBase(8) + MipmapHeader(16) + bitmap.
     MipmapHeader.streamSize is never initialised by the reference, so only bbox / level / bitmap are comparable."""

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle.refrun import have_ref, run_reference  # noqa: E402
+from tests.blobs import PP_KEEP  # noqa: E402
 from tests.images import edge_image, lineart_image, natural_photo, synth_planes  # noqa: E402
 
 PHOTO_SRC = "/opt/conda/lib/python3.9/site-packages/skimage/data/astronaut.png"       # present in the build image; never read by tests
@@ -38,8 +39,16 @@ HASHED = {  # name -> planes factory; SHA-256 per blob
     "lineart1024_rgba": lambda: lineart_image(1024, 4),          # procedurally drawn flat-colour illustration, anti-aliased edges
     "photo_astronaut256_rgb": natural_photo,                     # natural photograph (committed crop, see write_photo_input)
 }
+PARTIAL = {  # name -> planes factory; `ref_driver ... partial` (six partial-plane 4x4 passes after the RGB passes): pp_* + 1-D blobs kept
+    "pp_planemix128_rgb": lambda: edge_image(128, 128, "planemix", 3),
+    "pp_planemix144x80_rgb": lambda: edge_image(144, 80, "planemix", 3),
+    "pp_planemix256_rgba": lambda: edge_image(256, 256, "planemix", 4),
+    "pp_mixed128_rgba": lambda: edge_image(128, 128, "mixed", 4),
+}
 # blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
 DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_")
+# not hashed: wall-clock timings; chunks whose headers carry uninitialised reference memory (MipmapHeader.streamSize, EncoderContext.cpp:1367-1396)
+UNSTABLE = ("chunks_file", "stage_seconds", "mip_chunk")
 
 
 def write_photo_input():
@@ -61,11 +70,16 @@ def main():
         keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if not k.startswith(DROP_PREFIX)}
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
         print(name, sum(v.size for v in keep.values()), "bytes raw")
+    for name, mk in PARTIAL.items():
+        blobs = run_reference(mk(), partial=True)
+        keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if k.startswith(PP_KEEP)}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, sum(v.size for v in keep.values()), "bytes raw")
     hashes = {}
     for name, mk in HASHED.items():
         blobs = run_reference(mk())
         # chunks_file holds ZStd payloads and uninitialised header bytes: pinned in parsed form by tests/test_host_chunks.py, not by hash
-        hashes[name] = {k: hashlib.sha256(v).hexdigest() for k, v in blobs.items() if not k.startswith(DROP_PREFIX) and k != "chunks_file"}
+        hashes[name] = {k: hashlib.sha256(v).hexdigest() for k, v in blobs.items() if not k.startswith(DROP_PREFIX) and k not in UNSTABLE}
         hashes[name]["grad_counts_values"] = np.frombuffer(blobs["grad_counts"], np.int32).tolist()
     with open(os.path.join(HERE, "hashes.json"), "w") as f:
         json.dump(hashes, f, indent=1, sort_keys=True)

@@ -132,6 +132,13 @@ def edge_image(w: int, h: int, kind: str, n_planes: int = 3, seed: int = 7) -> n
             img = img + rng.normal(0, 2.5, (h, w)) * (fy > 0.5)
             chans.append(np.round(img))
         rgb = np.stack(chans)
+    elif kind == "planemix":
+        # per 16x16 block a subset of the channels is a smooth ramp and the rest noise: what the partial-plane gradient passes
+        # (FittingQuadSmooth with NULL planes) exist for; every subset 0..7 occurs, with block-aligned and 4-pixel-shifted borders
+        ramp = np.stack([(x * 255) // w, (y * 255) // h, ((x + y) * 255) // (w + h)])
+        sel = (((x + 4 * ((y // 32) & 1)) // 16) * 3 + (y // 16) * 5) % 8
+        noise = rng.integers(0, 256, (3, h, w))
+        rgb = np.stack([np.where((sel >> c) & 1, ramp[c], noise[c]) for c in range(3)])
     elif kind == "twocolor":
         a = rng.integers(0, 256, 3); b = rng.integers(0, 256, 3)
         sel = ((x * 7 + y * 13) // 5) % 2

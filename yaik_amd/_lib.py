@@ -60,6 +60,10 @@ SIGNATURES = {
     "yk_gradient_counts": (C.c_int, [vp, vp]),
     "yk_coverage": (C.c_int, [vp, vp, sz]),
     "yk_gradient_corners": (C.c_int, [vp, C.c_int, vp, sz, szp]),
+    "yk_gradient_partial_pass": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "yk_partial_bitmap": (C.c_int, [vp, vp, sz, szp]),
+    "yk_partial_corners": (C.c_int, [vp, vp, sz, szp]),
+    "yk_coverage_plane": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_gradient_corner_edges": (C.c_int, [vp, vp, vp, sz]),
     "yk_range_sizes": (C.c_int, [vp, C.c_int, szp, szp]),
     "yk_range_streams": (C.c_int, [vp, C.c_int, vp, sz, vp, sz]),
@@ -85,6 +89,8 @@ SIGNATURES = {
     "yk_decode_output": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_output_reference_rgba": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
+    "yk_decode_tile4x4_planes": (C.c_int, [vp, vp, sz]),
+    "yk_decode_gradient_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz]),
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
     "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),

@@ -97,6 +97,12 @@ struct yk_ctx {
     uint32_t* cornerEdgeIdx = nullptr;  // [2][w/4+1]: emission index (in corners, within its pass) of the first / last lattice row
     bool cornersReady = false; int nextCornerPass = 0;
     size_t cornerOff[7] = {}, cornerBytes[7] = {};
+    // partial-plane gradient passes (FittingQuadSmooth with nullable planes): per-plane coverage (mapSmoothTile[p], u16 per 16x16 tile, bit = cell)
+    // and per-plane "corner already emitted" flags per lattice point (mappedRGB[p]); allocated by the first partial pass after an encode
+    uint16_t* covCh = nullptr; size_t covChStride = 0;     // [3][covChStride]
+    uint8_t* mapped3 = nullptr;                            // bit p = plane p's corner at this lattice point has been emitted
+    uint32_t* ppBitmap = nullptr; size_t ppBitmapBytes = 0; uint8_t* ppStream = nullptr; size_t ppStreamCap = 0, ppStreamBytes = 0;
+    uint32_t* ppScratch = nullptr; size_t ppScratchElems = 0, ppBitmapCap = 0; int ppAccepted = 0; bool ppActive = false;
     // live 1-D range path (a15)
     uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
     uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;

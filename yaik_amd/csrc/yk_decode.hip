@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void yk_dec_owner_kernel(const uint32_t* __res
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const size_t li = (size_t)((y >> 2) + ((k & 2) ? dy : 0)) * latW + (x >> 2) + ((k & 1) ? dx : 0);
-        if (!loaded[li]) atomicMin(&owner[li], ((uint32_t)pos << 2) | (uint32_t)k);
+        if (!(loaded[li] & 1)) atomicMin(&owner[li], ((uint32_t)pos << 2) | (uint32_t)k);      // mapRGBMask plane 0 (hasRGB)
     }
 }
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __r
         if (!((own >> k) & 1u)) continue;
 #pragma unroll
         for (int c = 0; c < 3; c++) mapRGB[li[k] * 3 + c] = (off + c < rgbBytes) ? rgb[off + c] : 0;
-        loaded[li[k]] = 1;
+        loaded[li[k]] |= 1;
         off += 3;
     }
 }
@@ -135,6 +135,100 @@ __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __re
     }
 }
 
+// ---- partial planes: DecompressGradient4x4R / G / B / RG / GB / RB (decoder/YAIK_Gradient.cpp:1208-1226, :1420-2732) ------------
+// `loaded` holds one bit per plane and lattice point (the three planes of mapRGBMask); the masks are split first (UpdateTileAndRGBMask).
+__global__ void yk_dec_split_kernel(uint8_t* __restrict__ loaded, size_t lat, uint8_t* __restrict__ tile4, size_t tile4Size) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < lat) loaded[i] = (loaded[i] & 1) ? 7 : 0;                           // planes 1, 2 <- plane 0 (YAIK_API.cpp:536-537)
+    if (i < tile4Size) { const uint8_t v = tile4[i]; tile4[tile4Size + i] = v; tile4[2 * tile4Size + i] = v; }     // :539-540
+}
+// 4x4 tiles: 32x32 swizzle blocks of 64 tiles, bit t -> tile (t % 8, t / 8)
+__device__ __forceinline__ bool yk_d44_tile(const uint32_t* bitmap, size_t nBits, size_t pos, int w, int h, int& x, int& y) {
+    if (pos >= nBits || !((bitmap[pos >> 5] >> (pos & 31)) & 1u)) return false;
+    const int xBB = (w + 31) / 32;
+    const uint32_t blk = (uint32_t)(pos >> 6), t = (uint32_t)(pos & 63);
+    x = (int)(blk % xBB) * 32 + (int)(t & 7) * 4; y = (int)(blk / xBB) * 32 + (int)(t >> 3) * 4;
+    return x < w && y < h;
+}
+__global__ __launch_bounds__(256) void yk_dec44p_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, int w, int h, int latW, int planeBit,
+                                                              const uint8_t* __restrict__ loaded, uint32_t* __restrict__ owner) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int x, y;
+    if (!yk_d44_tile(bitmap, nBits, pos, w, h, x, y)) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t li = (size_t)((y >> 2) + (k >> 1)) * latW + (x >> 2) + (k & 1);
+        if ((~loaded[li]) & planeBit) atomicMin(&owner[li], ((uint32_t)pos << 2) | (uint32_t)k);      // some present plane still lacks this point
+    }
+}
+// EMIT=false: bytes popped per workgroup of 1024 tile slots; EMIT=true: pop them (per corner TL,TR,BL,BR, per present plane in R,G,B
+// order, only planes that lack the point, e.g. :1516-1580), then mark the point for the present planes
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void yk_dec44p_corner_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, int w, int h, int latW, int planeBit,
+                                                                uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums,
+                                                                const uint8_t* __restrict__ rgb, size_t rgbBytes, uint8_t* __restrict__ mapRGB) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t pos = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    int x = 0, y = 0;
+    const bool set = yk_d44_tile(bitmap, nBits, pos, w, h, x, y);
+    uint32_t need[4] = { 0, 0, 0, 0 }, bytes = 0;
+    size_t li[4] = { 0, 0, 0, 0 };
+    if (set) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            li[k] = (size_t)((y >> 2) + (k >> 1)) * latW + (x >> 2) + (k & 1);
+            if (owner[li[k]] == (((uint32_t)pos << 2) | (uint32_t)k)) { need[k] = (uint32_t)((~loaded[li[k]]) & planeBit); bytes += (uint32_t)__popc(need[k]); }
+        }
+    }
+    uint32_t tot;
+    const uint32_t ex = yk_block_exscan(bytes, s_tmp, &tot);
+    if (!EMIT) { if (threadIdx.x == 0) blockSums[blockIdx.x] = tot; return; }
+    uint32_t off = blockSums[blockIdx.x] + ex;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!need[k]) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) if ((need[k] >> c) & 1u) { mapRGB[li[k] * 3 + c] = off < rgbBytes ? rgb[off] : 0; off++; }
+    }
+}
+__global__ __launch_bounds__(256) void yk_dec44p_mark_kernel(const uint32_t* __restrict__ owner, size_t lat, int planeBit, uint8_t* __restrict__ loaded) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < lat && owner[i] != 0xFFFFFFFFu) loaded[i] |= (uint8_t)planeBit;    // every touched point now has the present planes
+}
+// fill (truncating integer bilinear, e.g. :1617-1640) + tile4x4Mask marking.  consistentMarks = 0 reproduces what the reference's loops
+// do to the mask: R / G / B never mark, GB / RB put the B marks at tile4x4Mask + (tile4x4MaskSize >> 1) (:1678, :1924).
+__global__ __launch_bounds__(256) void yk_dec44p_render_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, int w, int h, int latW, int planeBit, int consistentMarks,
+                                                               const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                               uint32_t* __restrict__ tile4, size_t tile4Size, int stride4) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int x, y;
+    if (!yk_d44_tile(bitmap, nBits, pos, w, h, x, y)) return;
+    const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
+    for (int c = 0; c < 3; c++) {
+        if (!((planeBit >> c) & 1)) continue;
+        const int TL = mapRGB[l0 * 3 + c], TR = mapRGB[(l0 + 1) * 3 + c], BL = mapRGB[(l0 + latW) * 3 + c], BR = mapRGB[(l0 + latW + 1) * 3 + c];
+        uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(y >> 3) * tileW + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7);
+#pragma unroll
+        for (int ty = 0; ty < 4; ty++) {
+            const int L = TL * (4 - ty) + BL * ty, R = TR * (4 - ty) + BR * ty;
+            uint32_t v4 = 0;
+#pragma unroll
+            for (int tx = 0; tx < 4; tx++) v4 |= (uint32_t)(((L * (4 - tx) + R * tx) >> 4) & 255) << (8 * tx);
+            *reinterpret_cast<uint32_t*>(o + ty * 8) = v4;
+        }
+        size_t base;
+        if (consistentMarks) base = tile4Size * c;
+        else {
+            if (planeBit == 1 || planeBit == 2 || planeBit == 4) continue;
+            base = (c == 2) ? (tile4Size >> 1) : tile4Size * c;
+        }
+        const int cx = x >> 2, cy = y >> 2;
+        const size_t byteIdx = base + (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
+        const uint32_t bit = (uint32_t)((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+        atomicOr(&tile4[byteIdx >> 2], 1u << (bit + 8 * (byteIdx & 3)));
+    }
+}
+
 // ---- 1-D range decode -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
                                                               uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
@@ -155,11 +249,14 @@ __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
                                                         const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
                                                         const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
-                                                        uint8_t* __restrict__ planes, size_t planeSize) {
+                                                        uint8_t* __restrict__ planes, size_t planeSize, int planeOverride, const uint32_t* __restrict__ runBase) {
     __shared__ uint32_t s_tmp[32];
     __shared__ uint32_t s_offT[1024], s_offP[1024];
     __shared__ uint8_t s_q[1024];
-    const int p = blockIdx.y;
+    // planeOverride < 0: the three planes share one mask (no partial-plane pass ran): plane = blockIdx.y, its streams start at
+    // plane * totals.  Otherwise one plane per launch with its own mask, streams start at runBase (tiles, pixels of the planes before it).
+    const int p = planeOverride < 0 ? (int)blockIdx.y : planeOverride;
+    const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
     const size_t i0 = (size_t)blockIdx.x * 1024;
     {
         const size_t i = i0 + threadIdx.x;
@@ -187,8 +284,8 @@ __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restric
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1), nBot = 2 - ((q >> 2) & 1) - ((q >> 3) & 1);
         const bool leftPresent = !((q >> (half * 2)) & 1);
         // stream order: half 0 rows (left then right quadrant of each row), then half 1 (:95-124)
-        const size_t po = (size_t)p * totals[1] + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)r * 4 * (half ? nBot : nTop) + ((side && leftPresent) ? 4 : 0);
-        const size_t to = ((size_t)p * totals[0] + s_offT[t]) * 3;
+        const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)r * 4 * (half ? nBot : nTop) + ((side && leftPresent) ? 4 : 0);
+        const size_t to = (baseT + s_offT[t]) * 3;
         if (to + 2 >= typeBytes) continue;
         const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
@@ -285,11 +382,12 @@ int yk_decode_begin(yk_ctx* c, int w, int h) {
     YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3));
     YK_HIP(c, hipMalloc(&c->dLatticeOwner, lat * 4));
     YK_HIP(c, hipMalloc(&c->dLoaded, lat));
-    YK_HIP(c, hipMalloc(&c->dTile4, ((c->dTile4Size + 3) & ~(size_t)3) + 4));
+    YK_HIP(c, hipMalloc(&c->dTile4, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4));       // three planes once the masks are split
     YK_HIP(c, hipMemsetAsync(c->dPlanes, 0, c->dPlaneSize * 3, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dMapRGB, 0, lat * 3, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dLoaded, 0, lat, c->stream));
-    YK_HIP(c, hipMemsetAsync(c->dTile4, 0, ((c->dTile4Size + 3) & ~(size_t)3) + 4, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dTile4, 0, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4, c->stream));
+    c->dSplit = false;
     return YK_OK;
 }
 
@@ -332,6 +430,54 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     return YK_OK;
 }
 
+static int yk_dec_split(yk_ctx* c) {                                       // UpdateTileAndRGBMask (YAIK_API.cpp:530-544), once
+    if (c->dSplit) return YK_OK;
+    const size_t lat = (size_t)(c->dw / 4 + 1) * (c->dh / 4 + 1), n = lat > c->dTile4Size ? lat : c->dTile4Size;
+    hipLaunchKernelGGL(yk_dec_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dLoaded, lat, c->dTile4, c->dTile4Size);
+    YK_HIP(c, hipGetLastError());
+    c->dSplit = true;
+    return YK_OK;
+}
+
+int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes) {
+    if (!c || !bitmap) return YK_ERR_BAD_ARG;
+    if (planeBit == 7) return yk_decode_gradient(c, 2, 2, bitmap, bitmapBytes, rgb, rgbBytes);
+    if (planeBit < 1 || planeBit > 6) return yk_fail(c, YK_ERR_BAD_ARG, "planeBit must be 1..7");
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    YK_HIP(c, hipSetDevice(c->device));
+    const int w = c->dw, h = c->dh, latW = w / 4 + 1;
+    const size_t lat = (size_t)latW * (h / 4 + 1);
+    const size_t need = ((size_t)((w + 31) / 32) * ((h + 31) / 32) * 64) >> 3;
+    if (bitmapBytes < need) return yk_fail(c, YK_ERR_RANGE, "tile bitmap shorter than the image needs");
+    const size_t nWords = (need + 3) / 4, nBits = need * 8, nb = (nBits + 1023) / 1024;
+    const size_t oB = 0, oR = oB + nWords * 4 + 16, oBB = (oR + rgbBytes + 19) & ~(size_t)15, oT = oBB + nb * 4 + 16;
+    int rc = yk_dec_scratch(c, oT + 64); if (rc) return rc;
+    rc = yk_dec_split(c); if (rc) return rc;                                 // a chunk whose plane field is not 7 splits the masks first (:875-877)
+    uint8_t* S = c->dScratch;
+    YK_HIP(c, hipMemsetAsync(S + oB, 0, nWords * 4, c->stream));
+    YK_HIP(c, hipMemcpyAsync(S + oB, bitmap, need, hipMemcpyHostToDevice, c->stream));
+    if (rgbBytes) YK_HIP(c, hipMemcpyAsync(S + oR, rgb, rgbBytes, hipMemcpyHostToDevice, c->stream));
+    YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
+    const uint32_t* bm = reinterpret_cast<const uint32_t*>(S + oB);
+    uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oBB);
+    uint32_t* total = reinterpret_cast<uint32_t*>(S + oT);
+    const unsigned g256 = (unsigned)((nBits + 255) / 256);
+    hipLaunchKernelGGL(yk_dec44p_owner_kernel, dim3(g256), dim3(256), 0, c->stream, bm, nBits, w, h, latW, planeBit, c->dLoaded, c->dLatticeOwner);
+    hipLaunchKernelGGL(yk_dec44p_corner_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nBits, w, h, latW, planeBit, c->dLoaded, c->dLatticeOwner,
+                       blockSums, (const uint8_t*)nullptr, (size_t)0, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, (int)nb, total);
+    hipLaunchKernelGGL(yk_dec44p_corner_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, bm, nBits, w, h, latW, planeBit, c->dLoaded, c->dLatticeOwner,
+                       blockSums, S + oR, rgbBytes, c->dMapRGB);
+    hipLaunchKernelGGL(yk_dec44p_mark_kernel, dim3((unsigned)((lat + 255) / 256)), dim3(256), 0, c->stream, c->dLatticeOwner, lat, planeBit, c->dLoaded);
+    hipLaunchKernelGGL(yk_dec44p_render_kernel, dim3(g256), dim3(256), 0, c->stream, bm, nBits, w, h, latW, planeBit, consistentMarks, c->dMapRGB, c->dPlanes,
+                       c->dPlaneSize, w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), c->dTile4Size, (w + 15) >> 4);
+    YK_HIP(c, hipGetLastError());
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
+}
+
+__global__ void yk_dec1d_next_plane_kernel(uint32_t* __restrict__ runBase, const uint32_t* __restrict__ tot) { if (threadIdx.x < 2) runBase[threadIdx.x] += tot[threadIdx.x]; }
+
 int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes, int compressionRange) {
     if (!c || !typeStream || !pixStream || compressionRange <= 0) return YK_ERR_BAD_ARG;
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
@@ -348,13 +494,32 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
-    hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP);
-    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
-    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
-    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
-    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
-    hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
-                       S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize);
+    if (!c->dSplit) {
+        // no partial-plane pass ran: the three planes share one mask, one count / scan serves all of them
+        hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP);
+        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
+        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
+        hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
+                           S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, -1, (const uint32_t*)nullptr);
+    } else {
+        // per-plane masks (Decompress1D reads tile4x4Mask + planeID * tile4x4MaskSize, YAIK_3DTile.cpp:41): one plane after the other,
+        // every plane's streams start where the plane before it stopped
+        uint32_t* runBase = tot + 4;
+        YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
+        for (int p = 0; p < 3; p++) {
+            const uint8_t* t4 = c->dTile4 + (size_t)p * c->dTile4Size;
+            hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, cT, cP);
+            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
+            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
+            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
+            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
+            hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
+                               S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, p, (const uint32_t*)runBase);
+            hipLaunchKernelGGL(yk_dec1d_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
+        }
+    }
     YK_HIP(c, hipGetLastError());
     { int rc2 = yk_stage_end(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     YK_HIP(c, hipStreamSynchronize(c->stream));
@@ -427,6 +592,16 @@ const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize) {
     if (!c || !c->dPlanes) return nullptr;
     if (planeSize) *planeSize = c->dPlaneSize;
     return c->dPlanes;
+}
+
+int yk_decode_tile4x4_planes(yk_ctx* c, uint8_t* hostOut, size_t cap) {     // the three planes of tile4x4Mask (planes 1, 2 are meaningful once split)
+    if (!c || !hostOut) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    if (cap < 3 * c->dTile4Size) return yk_fail(c, YK_ERR_RANGE, "tile4x4 buffer too small");
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(hostOut, c->dTile4, 3 * c->dTile4Size, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    return YK_OK;
 }
 
 int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap) {

@@ -20,7 +20,9 @@ __device__ __forceinline__ int yk_r1_div(int n, int d) { return __float2int_rz((
 __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB,
                                                         int strideElems, int w, int h, const uint16_t* __restrict__ coverage, int mtW,
                                                         int tilesW, size_t T8, uint8_t* __restrict__ slots, uint8_t* __restrict__ params,
-                                                        uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
+                                                        uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix, int onlyPlane) {
+    // onlyPlane < 0: the three planes share `coverage` (no partial-plane pass ran).  Otherwise this launch codes plane `onlyPlane` alone
+    // against that plane's own coverage (mapSmoothTile->GetPlane(p), EncoderContext.cpp:9451-9465).
     __shared__ __attribute__((aligned(16))) uint32_t s_px[16 * 16];          // 16 rows x 64 pixels, one byte each
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[16 * 64];        // per tile: 256 byte-wide bins
     const int lane = threadIdx.x;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     const int posStep = 4 * (cyl ? nBot : nTop);
     const int32_t* planes[3] = { pR, pG, pB };
     const int g4 = (lane & 15) * 4, r0 = lane >> 4;
-    for (int p = 0; p < 3; p++) {
+    for (int p = (onlyPlane < 0 ? 0 : onlyPlane); p < (onlyPlane < 0 ? 3 : onlyPlane + 1); p++) {
         // ---- stage the strip of this plane as bytes -------------------------------------------------------------
         {
             const int gx = BX * 64 + g4;
@@ -145,10 +147,12 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
 __global__ __launch_bounds__(1024) void yk_range1d_pack_kernel(const uint32_t* __restrict__ cntTiles, const uint32_t* __restrict__ cntPix,
                                                                const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
                                                                const uint32_t* __restrict__ totals, size_t T8, const uint8_t* __restrict__ slots,
-                                                               const uint8_t* __restrict__ params, uint8_t* __restrict__ pixOut, uint8_t* __restrict__ typeOut) {
+                                                               const uint8_t* __restrict__ params, uint8_t* __restrict__ pixOut, uint8_t* __restrict__ typeOut,
+                                                               int planeOverride, const uint32_t* __restrict__ runBase) {
     __shared__ uint32_t s_tmp[32];
     __shared__ uint32_t s_offT[1024], s_offP[1024], s_n[1024];
-    const int p = blockIdx.y;
+    const int p = planeOverride < 0 ? (int)blockIdx.y : planeOverride;
+    const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
     const size_t i0 = (size_t)blockIdx.x * 1024;
     {
         const size_t i = i0 + threadIdx.x;
@@ -167,16 +171,18 @@ __global__ __launch_bounds__(1024) void yk_range1d_pack_kernel(const uint32_t* _
         if (i >= T8) break;
         const uint32_t n = s_n[t];
         if (!n) continue;
-        const size_t po = (size_t)p * totals[1] + s_offP[t];
+        const size_t po = baseP + s_offP[t];
         if ((uint32_t)piece * 16 < n)
             *reinterpret_cast<uint4*>(pixOut + po + piece * 16) = *reinterpret_cast<const uint4*>(slots + ((size_t)p * T8 + i) * 64 + piece * 16);
         if (piece == 0) {
-            const size_t to = ((size_t)p * totals[0] + s_offT[t]) * 3;
+            const size_t to = (baseT + s_offT[t]) * 3;
             const uint8_t* qp = params + ((size_t)p * T8 + i) * 4;
             typeOut[to] = qp[0]; typeOut[to + 1] = qp[1]; typeOut[to + 2] = qp[2];
         }
     }
 }
+
+__global__ void yk_r1_next_plane_kernel(uint32_t* __restrict__ runBase, const uint32_t* __restrict__ tot) { if (threadIdx.x < 2) runBase[threadIdx.x] += tot[threadIdx.x]; }
 
 extern "C" {
 
@@ -194,29 +200,51 @@ int yk_range1d_encode(yk_ctx* c) {
     }
     uint32_t* cT = c->r1Cnt; uint32_t* cP = cT + T8; uint32_t* bT = cP + T8; uint32_t* bP = bT + nb + 16; uint32_t* tot = bP + nb + 16;
     const unsigned nStrips = (unsigned)(((c->fullW + 63) / 64) * ((c->h + 15) / 16));
-    { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
-                       c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP);
-    { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
-    { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
-    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
-    hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
-    hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
-    hipLaunchKernelGGL(yk_range1d_pack_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, cT, cP, bT, bP, tot, T8, c->r1Slots, c->r1Params, c->r1Pix, c->r1Type);
-    YK_HIP(c, hipGetLastError());
-    { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
     uint32_t t[2];
-    YK_HIP(c, hipMemcpyAsync(t, tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
-    YK_HIP(c, hipStreamSynchronize(c->stream));
-    c->r1Tiles = t[0]; c->r1PixCount = t[1]; c->r1Ready = true;
+    if (!c->ppActive) {
+        { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
+        hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                           c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, -1);
+        { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
+        { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
+        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
+        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
+        hipLaunchKernelGGL(yk_range1d_pack_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, cT, cP, bT, bP, tot, T8, c->r1Slots, c->r1Params, c->r1Pix, c->r1Type,
+                           -1, (const uint32_t*)nullptr);
+        YK_HIP(c, hipGetLastError());
+        { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
+        YK_HIP(c, hipMemcpyAsync(t, tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        t[0] *= 3; t[1] *= 3;
+    } else {
+        // partial-plane passes ran: every plane has its own coverage, so its own counts, scans and stream offsets
+        uint32_t* runBase = tot + 4;
+        YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
+        for (int p = 0; p < 3; p++) {
+            hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                               c->fullW, c->h, c->covCh + (size_t)p * c->covChStride, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, p);
+            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
+            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
+            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
+            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
+            hipLaunchKernelGGL(yk_range1d_pack_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, cT, cP, bT, bP, tot, T8, c->r1Slots, c->r1Params, c->r1Pix, c->r1Type,
+                               p, (const uint32_t*)runBase);
+            hipLaunchKernelGGL(yk_r1_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
+        }
+        YK_HIP(c, hipGetLastError());
+        YK_HIP(c, hipMemcpyAsync(t, runBase, sizeof t, hipMemcpyDeviceToHost, c->stream));
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->r1Tiles = t[0]; c->r1PixCount = t[1]; c->r1Ready = true;          // tile-planes coded and pixel bytes, all three planes
     return YK_OK;
 }
 
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType) {
     if (!c) return YK_ERR_BAD_ARG;
     if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");
-    const size_t np = (size_t)c->r1PixCount * 3, nt = (size_t)c->r1Tiles * 9;
+    const size_t np = (size_t)c->r1PixCount, nt = (size_t)c->r1Tiles * 3;
     if (nPix) *nPix = np;
     if (nType) *nType = nt;
     YK_HIP(c, hipSetDevice(c->device));

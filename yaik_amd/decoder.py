@@ -40,6 +40,13 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_decode_gradient(self._h, sx, sy, bitmap.ctypes.data, bitmap.size,
                                                rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size))
 
+    def decompress_gradient_planes(self, plane_bit: int, bitmap: np.ndarray, rgb_dq: np.ndarray, consistent_marks: bool = False):
+        """DecompressGradient4x4 with planeBit 1..6; consistent_marks=False leaves tile4x4Mask as the reference's loops do (defects included)."""
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        rgb_dq = np.ascontiguousarray(rgb_dq, dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_gradient_planes(self._h, plane_bit, int(consistent_marks), bitmap.ctypes.data, bitmap.size,
+                                                      rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size))
+
     def decompress_1d(self, type_stream: np.ndarray, pix_stream: np.ndarray, compression_range: int = 15):
         t = np.ascontiguousarray(type_stream, dtype=np.uint8)
         p = np.ascontiguousarray(pix_stream, dtype=np.uint8)
@@ -80,8 +87,9 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_stage_ms(self._h, stage, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
-    def tile4x4(self) -> np.ndarray:
+    def tile4x4(self, all_planes: bool = False) -> np.ndarray:
         n = ((((self.w + 15) >> 4) << 2) * (((self.h + 7) >> 3) << 1)) >> 3
-        out = np.zeros(n, dtype=np.uint8)
-        _chk(self._h, lib().yk_decode_tile4x4(self._h, out.ctypes.data, n))
+        out = np.zeros(n * (3 if all_planes else 1), dtype=np.uint8)
+        fn = lib().yk_decode_tile4x4_planes if all_planes else lib().yk_decode_tile4x4
+        _chk(self._h, fn(self._h, out.ctypes.data, out.size))
         return out

@@ -174,6 +174,33 @@ class HipTileEncoder:
         _chk(self._h, lib().yk_gradient_corners(self._h, p, out.ctypes.data, cap, C.byref(nb)))
         return out[:nb.value].copy()
 
+    # ---- FittingQuadSmooth with NULL planes (EncoderContext.cpp:3710, call sites :9261-9415) ---------------
+    def fitting_quad_smooth_planes(self, plane_bit: int, sx: int = 2, sy: int = 2, reject_factor: int = 3):
+        """One more gradient pass over the planes of `plane_bit` (bit0/1/2 = R/G/B present), after encode_tiles().
+        Returns (tiles accepted, swizzled bitmap bytes, corner stream bytes) like the reference's TileDone / pFillBitMap / rgbStream."""
+        L = lib()
+        n = C.c_int()
+        _chk(self._h, L.yk_gradient_partial_pass(self._h, reject_factor, plane_bit, sx, sy, C.byref(n)))
+        nb = C.c_size_t()
+        _chk(self._h, L.yk_partial_bitmap(self._h, None, 0, C.byref(nb)))
+        bm = np.zeros(nb.value, dtype=np.uint8)
+        if bm.size:
+            _chk(self._h, L.yk_partial_bitmap(self._h, bm.ctypes.data, bm.size, None))
+        _chk(self._h, L.yk_partial_corners(self._h, None, 0, C.byref(nb)))
+        cs = np.zeros(nb.value, dtype=np.uint8)
+        if cs.size:
+            _chk(self._h, L.yk_partial_corners(self._h, cs.ctypes.data, cs.size, None))
+        return int(n.value), bm, cs
+
+    def coverage_plane(self, plane: int) -> np.ndarray:
+        """[h/4, w/4] bool: 4x4 cell of `plane` covered by an accepted tile (mapSmoothTile[plane] != 0)."""
+        mtw, mth = (self.w + 15) // 16, (self.h + 15) // 16
+        raw = np.zeros(mtw * mth, dtype=np.uint16)
+        _chk(self._h, lib().yk_coverage_plane(self._h, plane, raw.ctypes.data, raw.size))
+        bits = (raw.reshape(mth, mtw, 1) >> np.arange(16, dtype=np.uint16)) & 1
+        cells = bits.reshape(mth, mtw, 4, 4).transpose(0, 2, 1, 3).reshape(mth * 4, mtw * 4)
+        return cells[: self.h // 4, : self.w // 4].astype(bool)
+
     def gradient_corner_edges(self):
         """(keys[2, w/4+1], index[2, w/4+1]) of the stripe's first and last lattice rows (see yk_gradient_corner_edges)."""
         n = self.w // 4 + 1
