@@ -179,6 +179,9 @@ int yk_set_dst_fill(yk_ctx* c, int32_t fill);
  * per-tile parameter bytes color0,minCol,delta (`streamType`, :8503-8505).  colorCompression1D = 255, rangeCompression1D = 15. */
 int yk_range1d_encode(yk_ctx* c);
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType);
+/* where plane p's share of the two streams ends (bytes, cumulative): the cursor DynamicTileCompressor returns after plane p (:8521) and
+ * the end of its streamType entries.  Equal thirds unless a partial-plane pass gave the planes different coverage. */
+int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]);
 
 /* ---- tile-map export for the multi-GPU gather (new; the reference is single-process) -----------------------
  * Packs this handle's results into ONE caller-owned HBM buffer (device-to-device copies on the handle's stream) so
@@ -210,6 +213,9 @@ int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t*
  * per-plane coverage and therefore the 1-D streams behind such passes assume (with 0 the reference's own Decompress1D runs off them). */
 int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, const uint8_t* bitmap, size_t bitmapBytes,
                               const uint8_t* rgb, size_t rgbBytes);
+/* UpdateTileAndRGBMask alone (decoder/YAIK_API.cpp:530-544): what a plane-subset chunk of any OTHER tile shape still does before its
+ * decoder returns without work (YAIK_Gradient.cpp:29-36).  Idempotent. */
+int yk_decode_split_masks(yk_ctx* c);
 /* Decompress1D x3 planes (decoder/YAIK_3DTile.cpp:24-240) on the '1DTL' streams (type: 3 B/tile, pix: 1 B/pixel) */
 int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes,
                  int compressionRange);

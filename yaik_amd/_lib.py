@@ -73,6 +73,7 @@ SIGNATURES = {
     "yk_set_dst_fill": (C.c_int, [vp, C.c_int32]),
     "yk_range1d_encode": (C.c_int, [vp]),
     "yk_range1d_streams": (C.c_int, [vp, vp, sz, szp, vp, sz, szp]),
+    "yk_range1d_plane_ends": (C.c_int, [vp, vp, vp]),
     "yk_export_capacity": (sz, [vp]),
     "yk_export_tile_maps": (C.c_int, [vp, vp, sz, vp]),
     "yk_export_tile_maps_async": (C.c_int, [vp, vp, sz, vp, vp]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),
     "yk_decode_tile4x4_planes": (C.c_int, [vp, vp, sz]),
     "yk_decode_gradient_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz]),
+    "yk_decode_split_masks": (C.c_int, [vp]),
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
     "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),

@@ -106,6 +106,7 @@ struct yk_ctx {
     // live 1-D range path (a15)
     uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
     uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;
+    uint32_t r1EndTiles[3] = {}, r1EndPix[3] = {};       // cumulative per plane (equal thirds unless a partial-plane pass ran)
     // decode
     int dw = 0, dh = 0; uint8_t* dPlanes = nullptr; size_t dPlaneSize = 0;
     uint8_t* dMapRGB = nullptr; uint32_t* dLatticeOwner = nullptr; uint8_t* dTile4 = nullptr; size_t dTile4Size = 0;

@@ -439,6 +439,13 @@ static int yk_dec_split(yk_ctx* c) {                                       // Up
     return YK_OK;
 }
 
+int yk_decode_split_masks(yk_ctx* c) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    YK_HIP(c, hipSetDevice(c->device));
+    return yk_dec_split(c);
+}
+
 int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes) {
     if (!c || !bitmap) return YK_ERR_BAD_ARG;
     if (planeBit == 7) return yk_decode_gradient(c, 2, 2, bitmap, bitmapBytes, rgb, rgbBytes);

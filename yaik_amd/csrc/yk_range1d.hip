@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void yk_range1d_pack_kernel(const uint32_t* _
     }
 }
 
-__global__ void yk_r1_next_plane_kernel(uint32_t* __restrict__ runBase, const uint32_t* __restrict__ tot) { if (threadIdx.x < 2) runBase[threadIdx.x] += tot[threadIdx.x]; }
+__global__ void yk_r1_next_plane_kernel(uint32_t* __restrict__ runBase, const uint32_t* __restrict__ tot) { if (threadIdx.x < 2) runBase[2 + threadIdx.x] = runBase[threadIdx.x] + tot[threadIdx.x]; }
 
 extern "C" {
 
@@ -217,12 +217,13 @@ int yk_range1d_encode(yk_ctx* c) {
         { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
         YK_HIP(c, hipMemcpyAsync(t, tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
         YK_HIP(c, hipStreamSynchronize(c->stream));
+        for (int p = 0; p < 3; p++) { c->r1EndTiles[p] = t[0] * (p + 1); c->r1EndPix[p] = t[1] * (p + 1); }
         t[0] *= 3; t[1] *= 3;
     } else {
         // partial-plane passes ran: every plane has its own coverage, so its own counts, scans and stream offsets
-        uint32_t* runBase = tot + 4;
+        uint32_t* runBase = tot + 4;                                         // [4][2]: (tile-planes, pixel bytes) before plane p; [3] = totals
         YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < 3; p++, runBase += 2) {
             hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
                                c->fullW, c->h, c->covCh + (size_t)p * c->covChStride, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, p);
             hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
@@ -234,10 +235,20 @@ int yk_range1d_encode(yk_ctx* c) {
             hipLaunchKernelGGL(yk_r1_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
         }
         YK_HIP(c, hipGetLastError());
-        YK_HIP(c, hipMemcpyAsync(t, runBase, sizeof t, hipMemcpyDeviceToHost, c->stream));
+        uint32_t ends[8];
+        YK_HIP(c, hipMemcpyAsync(ends, tot + 4, sizeof ends, hipMemcpyDeviceToHost, c->stream));
         YK_HIP(c, hipStreamSynchronize(c->stream));
+        for (int p = 0; p < 3; p++) { c->r1EndTiles[p] = ends[2 * p + 2]; c->r1EndPix[p] = ends[2 * p + 3]; }
+        t[0] = ends[6]; t[1] = ends[7];
     }
     c->r1Tiles = t[0]; c->r1PixCount = t[1]; c->r1Ready = true;          // tile-planes coded and pixel bytes, all three planes
+    return YK_OK;
+}
+
+int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]) {
+    if (!c) return YK_ERR_BAD_ARG;
+    if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");
+    for (int p = 0; p < 3; p++) { if (pixEnd) pixEnd[p] = c->r1EndPix[p]; if (typeEnd) typeEnd[p] = (size_t)c->r1EndTiles[p] * 3; }
     return YK_OK;
 }
 

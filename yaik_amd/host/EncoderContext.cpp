@@ -95,8 +95,31 @@ bool EncoderContext::ensureEncoded(int rejectFactor, bool mode3, bool wantDst) {
 int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* /*testOutput*/, bool useYCoCg,
                                       int tileBitSizeX, int tileBitSizeY) {
     if (!bound) { fail("FittingQuadSmooth: SetImageToEncode first"); return 0; }
-    if (a != original->GetPlane(0) || b != original->GetPlane(1) || c != original->GetPlane(2) || useYCoCg) {
-        fail("FittingQuadSmooth: only the full RGB pass (planes 0,1,2 of the image) is on this path"); return 0;
+    if (useYCoCg) { fail("FittingQuadSmooth: the YCoCg variant is not on this path"); return 0; }
+    if ((a && a != original->GetPlane(0)) || (b && b != original->GetPlane(1)) || (c && c != original->GetPlane(2)) || (!a && !b && !c)) {
+        fail("FittingQuadSmooth: srcA/B/C must be planes 0/1/2 of the image or NULL"); return 0;
+    }
+    const int planeBit = (a ? 1 : 0) | (b ? 2 : 0) | (c ? 4 : 0);           // PlaneBit (:3715)
+    if (planeBit != 7) {
+        // a pass over a subset of the planes (Convert()'s RB, RG, GB, R, G, B 4x4 passes, :9261-9415): it continues from the state the
+        // seven RGB passes left, so those come first
+        if (!encoded || nextPass != 7) { fail("FittingQuadSmooth: partial-plane passes follow the seven RGB passes"); return 0; }
+        int tiles = 0;
+        if (yk_gradient_partial_pass(ctx, rejectFactor, planeBit, tileBitSizeX, tileBitSizeY, &tiles) != YK_OK) { fail("yk_gradient_partial_pass"); return 0; }
+        oneDReady = false;
+        size_t nb = 0;
+        yk_partial_bitmap(ctx, nullptr, 0, &nb); gradBitmap.resize(nb);
+        if (nb && yk_partial_bitmap(ctx, gradBitmap.data(), nb, nullptr) != YK_OK) { fail("yk_partial_bitmap"); return 0; }
+        yk_partial_corners(ctx, nullptr, 0, &nb); gradRgb.resize(nb);
+        if (nb && yk_partial_corners(ctx, gradRgb.data(), nb, nullptr) != YK_OK) { fail("yk_partial_corners"); return 0; }
+        if (outFile && !evaluateLUT) {
+            std::string e;
+            const long before = ftell(outFile);
+            if (yaikchunk::writeGradientTile(outFile, original->GetWidth(), original->GetHeight(), tileBitSizeX, tileBitSizeY, gradBitmap.data(),
+                                             gradBitmap.size(), gradRgb.data(), gradRgb.size(), colorCompressionQuad, planeBit, e) < 0) { fail(("FittingQuadSmooth: " + e).c_str()); return 0; }
+            fileOutSize += (int)(ftell(outFile) - before);
+        }
+        return tiles;
     }
     int pass = -1;
     for (int i = 0; i < 7; i++) if (kPass[i][0] == tileBitSizeX && kPass[i][1] == tileBitSizeY) pass = i;
@@ -165,8 +188,10 @@ u8* EncoderContext::DynamicTileCompressor(u8* stream, Plane* src, Plane* /*map*/
         if (yk_range1d_streams(ctx, pix1d.data(), np, nullptr, type1d.data(), nt, nullptr) != YK_OK) { fail("yk_range1d_streams"); return stream; }
         oneDReady = true;
     }
-    const size_t per = pix1d.size() / 3;                                   // coverage is shared by the three planes
-    memcpy(stream, pix1d.data() + per * p, per);
+    size_t pixEnd[3] = {0, 0, 0};                                          // equal thirds unless a partial-plane pass ran
+    if (yk_range1d_plane_ends(ctx, pixEnd, nullptr) != YK_OK) { fail("yk_range1d_plane_ends"); return stream; }
+    const size_t from = p ? pixEnd[p - 1] : 0, per = pixEnd[p] - from;
+    memcpy(stream, pix1d.data() + from, per);
     return stream + per;
 }
 

@@ -3,6 +3,8 @@
 // the MI355X drop-in.  tests/test_gpu_host_mirror.py checks its output blob by blob.
 //
 // usage: host_driver <in.bin> <out.blobs> [mode3BitOnly] [out.yaik]
+//        host_driver <in.bin> <out.blobs> pp        the six plane-subset 4x4 passes of Convert() (:9261-9415) after the RGB passes, written
+//                                                   as a .yaik stream and decoded back (see run_partial below)
 // With the 4th argument the image is also converted to a .yaik stream (ConvertHotPath) and decoded back through the
 // YAIK_* decoder API, the way an application would use the two libraries.
 #include <cstdio>
@@ -11,6 +13,8 @@
 #include <vector>
 #include "EncoderContext.h"
 #include "yaik_decode.h"
+#include "chunks.h"
+#include "palette.h"
 
 static FILE* gOut;
 static void blob(const std::string& name, const void* data, size_t len) {
@@ -18,6 +22,68 @@ static void blob(const std::string& name, const void* data, size_t len) {
     fwrite(&nl, 4, 1, gOut); fwrite(name.data(), 1, nl, gOut); fwrite(&dl, 8, 1, gOut); if (len) fwrite(data, 1, len, gOut);
 }
 static std::string nm(const char* b, int a, int c = -1) { char t[96]; if (c >= 0) snprintf(t, sizeof t, "%s_%d_%d", b, a, c); else snprintf(t, sizeof t, "%s_%d", b, a); return t; }
+
+// FittingQuadSmooth with NULL planes, the way Convert() lists those calls (RB, RG, GB, R, G, B at 4x4), then the 1-D compressor on the
+// per-plane maps; the chunks go to a .yaik stream which is decoded back with consistent tile marks (YAIK_SetPartialPlaneMarks)
+static int run_partial(EncoderContext* ctx, Image* img, int w, int h, int np) {
+    FILE* yf = tmpfile(); if (!yf) return 2;
+    PaletteResetCodeBook();
+    if (!yaikchunk::writeFileHeader(yf, w, h, np == 4)) return 2;
+    ctx->outFile = yf;
+    if (np == 4) ctx->MipPrefilter(true);
+    static const int passes[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    for (int i = 0; i < 7; i++) ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), nullptr, false, passes[i][0], passes[i][1]);
+    static const int masks[6] = { 5, 3, 6, 1, 2, 4 };
+    int counts[6];
+    for (int i = 0; i < 6; i++) {
+        const int m = masks[i];
+        counts[i] = ctx->FittingQuadSmooth(3, (m & 1) ? img->GetPlane(0) : nullptr, (m & 2) ? img->GetPlane(1) : nullptr, (m & 4) ? img->GetPlane(2) : nullptr,
+                                           nullptr, false, 2, 2);
+        blob(nm("pp_bitmap", i), ctx->LastGradientBitmap().data(), ctx->LastGradientBitmap().size());
+        blob(nm("pp_rgbraw", i), ctx->LastGradientRGBStream().data(), ctx->LastGradientRGBStream().size());
+    }
+    blob("pp_counts", counts, sizeof counts);
+    std::vector<u8> pix((size_t)w * h * 3 + 64);
+    u8* wr = pix.data();
+    int ends[3];
+    for (int p = 0; p < 3; p++) { wr = ctx->DynamicTileCompressor(wr, img->GetPlane(p), nullptr, nullptr); ends[p] = (int)(wr - pix.data()); }
+    blob("d1_pix", pix.data(), (size_t)(wr - pix.data()));
+    blob("d1_type", ctx->TileTypeStream1D().data(), ctx->TileTypeStream1D().size());
+    blob("d1_pix_ends", ends, sizeof ends);
+    ctx->GenerateDynamicTileChunk(pix.data(), (int)(wr - pix.data()));
+    if (*ctx->LastError()) { fprintf(stderr, "%s\n", ctx->LastError()); return 4; }
+    if (!yaikchunk::writeEndOfFile(yf)) return 2;
+    ctx->outFile = nullptr;
+    fflush(yf);
+    const long n = ftell(yf);
+    std::vector<u32> stream(((size_t)n + 3) / 4);
+    fseek(yf, 0, SEEK_SET);
+    if (fread(stream.data(), 1, (size_t)n, yf) != (size_t)n) return 2;
+    fclose(yf);
+    blob("yaik_file", stream.data(), (size_t)n);
+    if ((w & 15) || (h & 15)) return 0;
+    YAIK_LIB lib = YAIK_Init(1, nullptr);
+    if (!lib) return 5;
+    static std::vector<u8> tiled;
+    for (int consistent = 0; consistent < 2; consistent++) {
+        YAIK_SetPartialPlaneMarks(consistent);
+        YAIK_SDecodedImage di;
+        if (!YAIK_DecodeImagePre(lib, stream.data(), (u32)n, &di)) { fprintf(stderr, "Pre failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        std::vector<u8> outImg((size_t)di.width * di.height * 4);
+        di.outputImage = outImg.data(); di.outputImageStride = di.width * 4;
+        di.customImageOutput = [](YAIK_SDecodedImage* u, YAIK_SCustomDataSource* s) {
+            const size_t planeSize = (size_t)(u->width / 8) * (u->height / 8) * 64;
+            tiled.assign(s->planeR, s->planeR + planeSize);
+            tiled.insert(tiled.end(), s->planeG, s->planeG + planeSize);
+            tiled.insert(tiled.end(), s->planeB, s->planeB + planeSize);
+        };
+        if (!YAIK_DecodeImage(stream.data(), (u32)n, &di)) { fprintf(stderr, "Decode failed: %d\n", (int)YAIK_GetErrorCode()); return 5; }
+        blob(nm("yaik_planes_tiled", consistent), tiled.data(), tiled.size());
+    }
+    YAIK_SetPartialPlaneMarks(0);
+    YAIK_Release(lib);
+    return 0;
+}
 
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: host_driver in.bin out.blobs [mode3]\n"); return 2; }
@@ -32,6 +98,12 @@ int main(int argc, char** argv) {
 
     EncoderContext* ctx = new EncoderContext();
     if (!ctx->SetImageToEncode(img)) { fprintf(stderr, "%s\n", ctx->LastError()); return 3; }
+    if (argc > 3 && std::string(argv[3]) == "pp") {
+        const int rc = run_partial(ctx, img, w, h, np);
+        fclose(gOut);
+        ctx->SetImageToEncode(nullptr); ctx->Release(); delete ctx;
+        return rc;
+    }
     ctx->outFile = tmpfile();                                      // the passes append their chunks here, like the reference's outFile
     if (!ctx->outFile) return 2;
     if (np == 4) {

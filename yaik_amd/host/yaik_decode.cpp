@@ -46,6 +46,8 @@ bool zexpand(const uint8_t* src, uint32_t n, uint32_t expected, std::vector<uint
 }
 
 void YAIK_SetDevice(int device) { gDevice = device; }
+static int gConsistentMarks = 0;
+void YAIK_SetPartialPlaneMarks(int consistent) { gConsistentMarks = consistent ? 1 : 0; }
 
 YAIK_LIB YAIK_Init(uint8_t maxDecodeThreadContext, YAIK_SMemAlloc* libraryMemAllocator) {
     if (maxDecodeThreadContext == 0) { setError(YAIK_INVALID_CONTEXT_COUNT); return nullptr; }
@@ -137,7 +139,7 @@ bool YAIK_DecodeImage(void* stream, uint32_t length, YAIK_SDecodedImage* info) {
                 HeaderGradientTile gh; memcpy(&gh, body, sizeof gh);
                 const int sx = gh.format & 7, sy = (gh.format >> 3) & 7;
                 u32 bigX, bigY, bitCount;
-                if (!swizzleSize(sx, sy, bigX, bigY, bitCount) || gh.plane != 7) { setError(YAIK_INVALID_PLANE_ID); bad = true; break; }
+                if (!swizzleSize(sx, sy, bigX, bigY, bitCount) || gh.plane < 1 || gh.plane > 7) { setError(YAIK_INVALID_PLANE_ID); bad = true; break; }
                 const uint8_t* after = body + sizeof gh;
                 if (after + (size_t)gh.streamBitmapSize + gh.streamRGBSizeZStd > endBlock) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
                 const uint32_t sizeBitmap = (uint32_t)(((w + bigX - 1) / bigX) * ((h + bigY - 1) / bigY) * bitCount / 8);
@@ -147,6 +149,14 @@ bool YAIK_DecodeImage(void* stream, uint32_t length, YAIK_SDecodedImage* info) {
                 rgb.assign((size_t)gh.streamRGBSizeUncompressed + slack, 0);
                 if (!PaletteDecompressor(pal.data(), (int)gh.streamRGBSizeCustomCompressor, (int)gh.streamRGBSizeCustomCompressor + 128 * 3, rgb.data(),
                                          (int)gh.streamRGBSizeUncompressed, gh.colorCompression)) { setError(YAIK_INVALID_STREAM); bad = true; break; }
+                if (gh.plane != 7) {
+                    // a chunk for one or two planes splits the masks per plane first (UpdateTileAndRGBMask, YAIK_API.cpp:876-878); only the 4x4
+                    // decoders exist for such chunks, every other tile shape returns without touching anything (YAIK_Gradient.cpp:29-36)
+                    if (yk_decode_split_masks(s->ctx) != YK_OK) { setError(YAIK_INVALID_STREAM); bad = true; break; }
+                    if (sx == 2 && sy == 2 && yk_decode_gradient_planes(s->ctx, gh.plane, gConsistentMarks, bitmap.data(), sizeBitmap, rgb.data(),
+                                                                       gh.streamRGBSizeUncompressed) != YK_OK) { setError(YAIK_INVALID_STREAM); bad = true; }
+                    break;
+                }
                 if (yk_decode_gradient(s->ctx, sx, sy, bitmap.data(), sizeBitmap, rgb.data(), gh.streamRGBSizeUncompressed) != YK_OK) { setError(YAIK_INVALID_STREAM); bad = true; }
                 break;
             }

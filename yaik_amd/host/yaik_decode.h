@@ -61,3 +61,8 @@ YAIK_ERROR_CODE YAIK_GetErrorCode();
 
 // extension (not in the reference): HIP device used by the decode slots created by the next YAIK_Init (default 0)
 void            YAIK_SetDevice(int device);
+// extension: how 'GTIL' chunks for one or two planes (HeaderGradientTile::plane 1..6) mark tile4x4Mask.  0 (default) = exactly what the
+// reference's DecompressGradient4x4R/G/B/RG/GB/RB loops do (R/G/B leave the mask alone, GB/RB put the B marks at tile4x4Mask +
+// tile4x4MaskSize/2; decoder/YAIK_Gradient.cpp:1420-2732), after which the reference's own Decompress1D reads a different number of
+// tiles than the encoder wrote; 1 = every pass marks the planes it filled, which decodes such streams correctly.
+void            YAIK_SetPartialPlaneMarks(int consistent);
