@@ -399,6 +399,9 @@ extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMem
 #endif
 #define YK2_LUTW 84
 
+// WANT_DST: the test-only reconstruction of the coded pixels into P.dst (yk_range_dst).  It is a separate instantiation because its extra
+// live state costs the product kernel 8 spilled VGPRs, and with them a scratch allocation per wave launch.
+template <bool WANT_DST>
 __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams P) {
     // One wave64 per workgroup: a work unit is a 64x16 strip (four macro-tiles) of a 64x64 swizzle block, so nothing in the
     // kernel waits on another wave.  The staged pixels are only read by the gradient passes (afterwards every lane holds its
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     } else {
         uint32_t* lut = &s_lut[tw][0];
         // curve constants for buildLut (test-only reconstruction); fetched here, off the path of the strip's pixel loads
-        if (P.wantDst) {
+        if (WANT_DST) {
             s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
             if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
         }
@@ -696,6 +699,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 #pragma unroll
         for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __fdiv_rn(1.0f, (float)v) : 0.0f; }   // correctly rounded: the exact path needs that
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t slotOff[4];                                                 // byte offset of the lane's four nibble rows inside the plane's slot array
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int yIn = cyl * 4 + r;
+            const int pos = (yIn < 4) ? (yIn * 4 * nTop + (cxl ? 4 * (int)v00 : 0))
+                                      : (16 * nTop + (yIn - 4) * 4 * nBot + (cxl ? 4 * (int)v01 : 0));
+            slotOff[r] = (uint32_t)tileIdx * (uint32_t)YK_SLOT + (uint32_t)(pos >> 1);
+        }
         for (int p = 0; p < 3; p++) {
             // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
             int mn = 99999999, mx = -99999999;
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
 #ifdef YK2_TIMING
             if (lane == 0 && unit < 65536 && ambMask) { g_y2_times[(size_t)unit * 16 + 10] += (unsigned long long)__popcll(ambMask) / 4; g_y2_times[(size_t)unit * 16 + 11] += 1; }
 #endif
-            if (P.wantDst) buildLut();
+            if (WANT_DST) buildLut();
             while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
                 const int al = __ffsll((long long)ambMask) - 1;              // a lane of the tile
                 const int ac = al & 15;
@@ -905,15 +916,16 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
             // codes of the best mode, nibble-packed at the position of the lane's pixels among the tile's valid pixels (:1174-1190)
             if (valid) {
-                uint8_t* slot = slotsP + ((size_t)p * T8 + tileIdx) * YK_SLOT;
+                uint8_t* const slotPlane = slotsP + (size_t)p * T8 * YK_SLOT;      // wave-uniform base + 32-bit lane offsets (3 * T8 * 32 < 2^32)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int yIn = cyl * 4 + r;
-                    const int pos = (yIn < 4) ? (yIn * 4 * nTop + (cxl ? 4 * (int)v00 : 0))
-                                              : (16 * nTop + (yIn - 4) * 4 * nBot + (cxl ? 4 * (int)v01 : 0));
                     const uint32_t code16 = ((r < 2 ? cLo : cHi) >> (16 * (r & 1))) & 0xFFFFu;
-                    *reinterpret_cast<uint16_t*>(slot + (pos >> 1)) = (uint16_t)code16;
-                    if (P.wantDst) {
+                    // the offsets do not depend on the plane; kept as four 32-bit registers and widened here, next to the store, so that
+                    // the store takes the scalar base + 32-bit offset form (hoisted 64-bit offsets cost 8 registers and a spill)
+                    uint32_t so = slotOff[r];
+                    asm volatile("" : "+v"(so));
+                    *reinterpret_cast<uint16_t*>(slotPlane + so) = (uint16_t)code16;
+                    if (WANT_DST) {
                         const uint32_t* lb = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
                         int32_t* drow = P.dst[p] + (uint32_t)((gyCell + r) * w + gxCell);     // 32-bit element offset from a scalar base (w, h <= 32760)
 #pragma unroll
@@ -959,7 +971,8 @@ int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
     // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
     YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
     dim3 grid(((nB + group - 1) / group) * group * 4);
-    hipLaunchKernelGGL(yk_encode2_kernel, grid, dim3(64), 0, c->stream, P);
+    if (P.wantDst) hipLaunchKernelGGL(yk_encode2_kernel<true>, grid, dim3(64), 0, c->stream, P);
+    else hipLaunchKernelGGL(yk_encode2_kernel<false>, grid, dim3(64), 0, c->stream, P);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
