@@ -5,8 +5,8 @@
 // emitted by any earlier tile of this or an earlier pass.  That is a first-toucher problem:
 //   1. owner[lattice point] = min over all accepted tiles touching it of key = pass<<27 | bitIndex<<2 | corner
 //      (bitIndex = the tile's position in the swizzled bitmap = the reference's scan order `pos`)        -- atomicMin
-//   2. per pass: every bitmap word counts the corners its tiles own, an exclusive scan gives the byte offsets,
-//      and the owners write CompressF(Round6(v),250) for R,G,B.
+//   2. every block of 1024 tile slots counts the corners its tiles own, ONE exclusive scan over the blocks of all passes gives the
+//      byte offsets (relative to the pass's first block), and the owners write CompressF(Round6(v),250) for R,G,B.
 // All bitmaps stay on the device; only the finished streams are copied out.
 #include "yk_common.h"
 #include "yk_device.h"
@@ -29,18 +29,42 @@ __device__ __forceinline__ void yk_tile_from_bit(const PassGeo& g, uint32_t pos,
     y = (int)(blk / g.xBB) * g.bigY + (int)(t / g.tilesPerRow) * (1 << g.sy);
 }
 
-__global__ __launch_bounds__(256) void yk_corner_owner_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, int pass, int w, int latW,
-                                                              uint32_t* __restrict__ owner) {
-    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= nWords) return;
-    uint32_t bits = bitmap[wi];
+// The seven passes share every launch: bitmap words (owner) and 1024-slot blocks (count / emit) of all passes are laid end to end.
+struct CornerPlan {
+    uint32_t wordStart[8];          // first bitmap word of pass p in the concatenated word space ([7] = total)
+    uint32_t blockStart[8];         // first 1024-slot block of pass p ([7] = total)
+    unsigned long long bits[7];     // tile slots of pass p
+    const uint32_t* bm[7];
+};
+__device__ __forceinline__ int yk_plan_find(const uint32_t (&start)[8], uint32_t i) {
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < 7; k++) p += (i >= start[k]) ? 1 : 0;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void yk_corner_owner_kernel(const CornerPlan pl, int w, int latW, uint32_t* __restrict__ owner) {
+    // One thread per bitmap byte (8 slots of one swizzle block: the block's coordinates are computed once, see yk_corner_stream_kernel).
+    // Measured alternatives on the 8192x8192 bench frame (131 k accepted 16x16 tiles): one thread per word 41 us, per byte 41 us, per byte
+    // with the atomics of corners a lower-positioned neighbour tile of the same pass also touches left out 47 us, per slot with that
+    // filter 51 us (16 us of it just starting 10.7 M threads): neither the atomics nor the serial tile loop is the cost.
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= pl.wordStart[7] * 4u) return;
+    const int pass = yk_plan_find(pl.wordStart, gi >> 2);
+    const uint32_t bi = gi - pl.wordStart[pass] * 4u;
+    const uint32_t byte = reinterpret_cast<const uint8_t*>(pl.bm[pass])[bi];
+    if (!byte) return;
     const PassGeo g = yk_pass_geo(pass, w);
-    while (bits) {
-        const int b = __ffs(bits) - 1; bits &= bits - 1;
-        const uint32_t pos = (uint32_t)(wi * 32 + b);
-        int x, y; yk_tile_from_bit(g, pos, x, y);
-        const int lx = x >> 2, ly = y >> 2, dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-        const uint32_t key = ((uint32_t)pass << 27) | (pos << 2);
+    const uint32_t pos0 = bi * 8u, blk = pos0 / (uint32_t)g.bitCount, t0 = pos0 % (uint32_t)g.bitCount;
+    const int bx0 = (int)(blk % (uint32_t)g.xBB) * g.bigX, by0 = (int)(blk / (uint32_t)g.xBB) * g.bigY;
+    const int tprShift = __ffs(g.tilesPerRow) - 1, dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (!((byte >> k) & 1u)) continue;
+        const uint32_t t = t0 + (uint32_t)k;
+        const int x = bx0 + (int)((t & (uint32_t)(g.tilesPerRow - 1)) << g.sx), y = by0 + (int)((t >> tprShift) << g.sy);
+        const int lx = x >> 2, ly = y >> 2;
+        const uint32_t key = ((uint32_t)pass << 27) | ((pos0 + (uint32_t)k) << 2);
         atomicMin(&owner[(size_t)ly * latW + lx], key | 0u);
         atomicMin(&owner[(size_t)ly * latW + lx + dx], key | 1u);
         atomicMin(&owner[(size_t)(ly + dy) * latW + lx], key | 2u);
@@ -48,49 +72,106 @@ __global__ __launch_bounds__(256) void yk_corner_owner_kernel(const uint32_t* __
     }
 }
 
-// One thread per tile slot (bit) of the pass's bitmap, 1024 slots per workgroup.  COUNT: corners owned per workgroup.
-// EMIT: exclusive scan inside the workgroup + the scanned workgroup bases = byte offset of every owned corner.
+// One thread per bitmap BYTE (8 tile slots), 1024 bytes per workgroup.  (Round 1 ran one thread per slot: a block scan per 1024 slots of
+// mostly empty maps cost more than the work it ordered; one thread per 32-bit word serialises 32 dependent gather rounds in the dense
+// 16x16 regions: 149 us for the emit launch.)  The 32 owner look-ups of a byte are issued together, unconditionally (slots that are not
+// set read entry 0 and are masked), so a thread waits for memory once.  COUNT: corners owned per thread (kept as bytes for the emit
+// launch) and per workgroup.  EMIT: exclusive scan inside the workgroup + the scanned workgroup bases (relative to the pass's first
+// block) = byte offset of the thread's first owned corner; a thread walks its tiles in bit order = the reference's scan order.
 template <bool EMIT>
-__global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const uint32_t* __restrict__ bitmap, size_t nBits, int pass, int w, int latW,
-                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums,
+__global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const CornerPlan pl, int w, int latW,
+                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums, uint8_t* __restrict__ perThread,
                                                                 const int32_t* const __restrict__ pR, const int32_t* const __restrict__ pG,
                                                                 const int32_t* const __restrict__ pB, int strideElems,
-                                                                uint8_t* __restrict__ out, uint32_t* __restrict__ edgeIdx, int latH, int hAvail) {
+                                                                uint8_t* __restrict__ out0, size_t region, uint32_t* __restrict__ edgeIdx, int latH, int hAvail) {
     __shared__ uint32_t s_tmp[32];
-    const size_t pos = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    const bool set = pos < nBits && ((bitmap[pos >> 5] >> (pos & 31)) & 1u);
+    const int pass = yk_plan_find(pl.blockStart, blockIdx.x);
+    const uint32_t bi = (blockIdx.x - pl.blockStart[pass]) * 1024u + threadIdx.x;           // byte of the pass's bitmap
+    const uint32_t nBytes = (pl.wordStart[pass + 1] - pl.wordStart[pass]) * 4u;
+    const size_t ti = (size_t)pl.wordStart[pass] * 4u + bi;                                   // thread index over all passes
+    const uint32_t byte = bi < nBytes ? reinterpret_cast<const uint8_t*>(pl.bm[pass])[bi] : 0u;
     const PassGeo g = yk_pass_geo(pass, w);
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    int x = 0, y = 0;
-    uint32_t own = 0, cnt = 0;
-    const uint32_t key = ((uint32_t)pass << 27) | ((uint32_t)pos << 2);
-    if (set) {
-        yk_tile_from_bit(g, (uint32_t)pos, x, y);
-        const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
-        own = (owner[l0] == (key | 0u) ? 1u : 0u) | (owner[l0 + dx] == (key | 1u) ? 2u : 0u) |
-              (owner[l0 + (size_t)dy * latW] == (key | 2u) ? 4u : 0u) | (owner[l0 + (size_t)dy * latW + dx] == (key | 3u) ? 8u : 0u);
-        cnt = (uint32_t)__popc(own);
+    uint32_t cnt = 0;
+    if (EMIT) cnt = bi < nBytes ? perThread[ti] : 0u;
+    uint32_t own[8];
+    int tx[8], ty[8];
+    if (!EMIT || cnt) {
+        uint32_t o[8][4];
+        // the 8 slots of a byte lie in one swizzle block (every block holds a multiple of 8 tiles); tiles per row / per block are powers of two
+        const uint32_t pos0 = bi * 8u, blk = pos0 / (uint32_t)g.bitCount, t0 = pos0 % (uint32_t)g.bitCount;
+        const int bx0 = (int)(blk % (uint32_t)g.xBB) * g.bigX, by0 = (int)(blk / (uint32_t)g.xBB) * g.bigY;
+        const int tprShift = __ffs(g.tilesPerRow) - 1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool set = (byte >> k) & 1u;
+            const uint32_t t = t0 + (uint32_t)k;
+            tx[k] = bx0 + (int)((t & (uint32_t)(g.tilesPerRow - 1)) << g.sx); ty[k] = by0 + (int)((t >> tprShift) << g.sy);
+            const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
+            const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
+            o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+            const bool set = (byte >> k) & 1u;
+            own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+        }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cnt += (uint32_t)__popc(own[k]);
+        uint32_t tot;
+        yk_block_exscan(cnt, s_tmp, &tot);
+        if (bi < nBytes) perThread[ti] = (uint8_t)cnt;
+        if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+        return;
     }
     uint32_t tot;
     const uint32_t ex = yk_block_exscan(cnt, s_tmp, &tot);
-    if (!EMIT) { if (threadIdx.x == 0) blockSums[blockIdx.x] = tot; return; }
-    uint32_t off = (blockSums[blockIdx.x] + ex) * 3u;
+    if (!cnt) return;
+    uint32_t off = (blockSums[blockIdx.x] - blockSums[pl.blockStart[pass]] + ex) * 3u;
+    uint8_t* __restrict__ out = out0 + region * pass;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (!((own >> k) & 1u)) continue;
-        const int lx = (x >> 2) + ((k & 1) ? dx : 0), ly = (y >> 2) + ((k & 2) ? dy : 0);
-        // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
-        const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
-        // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
-        if (ly == 0) edgeIdx[lx] = off / 3u;
-        if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
-        const int v[3] = { pR[src], pG[src], pB[src] };
+    for (int k = 0; k < 8; k++) {
+        if (!own[k]) continue;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
-            out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
+        for (int c4 = 0; c4 < 4; c4++) {
+            if (!((own[k] >> c4) & 1u)) continue;
+            const int lx = (tx[k] >> 2) + ((c4 & 1) ? dx : 0), ly = (ty[k] >> 2) + ((c4 & 2) ? dy : 0);
+            // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
+            const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
+            // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
+            if (ly == 0) edgeIdx[lx] = off / 3u;
+            if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
+            const int v[3] = { pR[src], pG[src], pB[src] };
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
+                out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
+            }
+            off += 3;
         }
-        off += 3;
+    }
+}
+
+// exclusive prefix of all block sums in place (one workgroup: thread t owns a run of consecutive blocks) + the corners per pass
+__global__ __launch_bounds__(1024) void yk_corner_scan_kernel(uint32_t* __restrict__ blockSums, const CornerPlan pl, uint32_t* __restrict__ passTotals) {
+    __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_total;
+    const uint32_t n = pl.blockStart[7], per = (n + 1023) / 1024;
+    const uint32_t a = min(threadIdx.x * per, n), b = min(a + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; i++) sum += blockSums[i];
+    uint32_t tot;
+    uint32_t run = yk_block_exscan(sum, s_tmp, &tot);
+    for (uint32_t i = a; i < b; i++) { const uint32_t v = blockSums[i]; blockSums[i] = run; run += v; }
+    if (threadIdx.x == 0) s_total = tot;
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const uint32_t lo = blockSums[pl.blockStart[threadIdx.x]];
+        const uint32_t hi = pl.blockStart[threadIdx.x + 1] < n ? blockSums[pl.blockStart[threadIdx.x + 1]] : s_total;
+        passTotals[threadIdx.x] = (pl.blockStart[threadIdx.x] < n) ? hi - lo : 0u;
     }
 }
 
@@ -105,31 +186,33 @@ int yk_launch_corners(yk_ctx* c) {
     // back; the passes are laid out at their worst-case offsets (pass p after everything passes < p could emit) = 7 regions
     const size_t region = lat * 3 + 16;
     if (!c->cornerStream) { c->cornerCap = region * 7; YK_HIP(c, hipMalloc(&c->cornerStream, c->cornerCap)); }
-    size_t nbTot = 0; size_t nbOf[7], bitsOf[7];
-    for (int p = 0; p < 7; p++) { bitsOf[p] = c->bitmapBytes[p] * 8; nbOf[p] = (bitsOf[p] + 1023) / 1024; nbTot += nbOf[p]; }
-    if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
+    CornerPlan pl;
+    pl.wordStart[0] = 0; pl.blockStart[0] = 0;
+    for (int p = 0; p < 7; p++) {
+        pl.bits[p] = (unsigned long long)c->bitmapBytes[p] * 8;
+        pl.bm[p] = reinterpret_cast<const uint32_t*>(c->bitmap[p]);
+        pl.wordStart[p + 1] = pl.wordStart[p] + (uint32_t)((c->bitmapBytes[p] + 3) / 4);   // bitmap allocations are padded by 16 bytes; pass 0 words may be half used
+        pl.blockStart[p + 1] = pl.blockStart[p] + ((pl.wordStart[p + 1] - pl.wordStart[p]) * 4u + 1023u) / 1024u;   // 1024 bitmap bytes per workgroup
+    }
+    const size_t nbTot = pl.blockStart[7], nWordsTot = pl.wordStart[7];
+    // scratch: [block sums | 7 totals (+ pad) | corners per thread (one byte per bitmap byte)]
+    if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64 + nWordsTot; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
+    uint32_t* blockSums = c->cornerScratch;
     uint32_t* totalDev = c->cornerScratch + nbTot;
+    uint8_t* perThread = reinterpret_cast<uint8_t*>(c->cornerScratch + nbTot + 64);
     if (!c->cornerEdgeIdx) YK_HIP(c, hipMalloc(&c->cornerEdgeIdx, (size_t)latW * 2 * 4));
     { int rc = yk_stage_begin(c, YK_STAGE_CORNERS); if (rc) return rc; }
     YK_HIP(c, hipMemsetAsync(c->cornerEdgeIdx, 0xFF, (size_t)latW * 2 * 4, c->stream));
     YK_HIP(c, hipMemsetAsync(c->latticeOwner, 0xFF, lat * 4, c->stream));
-    for (int p = 0; p < 7; p++) {
-        const size_t nWords = (c->bitmapBytes[p] + 3) / 4;      // bitmap allocations are padded by 16 bytes; pass 0 words may be half used
+    for (int p = 0; p < 7; p++)
         if (c->bitmapBytes[p] & 3) YK_HIP(c, hipMemsetAsync(c->bitmap[p] + c->bitmapBytes[p], 0, 4 - (c->bitmapBytes[p] & 3), c->stream));
-        hipLaunchKernelGGL(yk_corner_owner_kernel, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, c->stream,
-                           reinterpret_cast<const uint32_t*>(c->bitmap[p]), nWords, p, w, latW, c->latticeOwner);
-    }
-    uint32_t* blockSums = c->cornerScratch;
-    for (int p = 0; p < 7; p++) {
-        const unsigned nb = (unsigned)nbOf[p];
-        const uint32_t* bm = reinterpret_cast<const uint32_t*>(c->bitmap[p]);
-        hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3(nb), dim3(1024), 0, c->stream, bm, bitsOf[p], p, w, latW, c->latticeOwner, blockSums,
-                           c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr, (uint32_t*)nullptr, latH, c->h + c->halo);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, (int)nb, totalDev + p);
-        hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3(nb), dim3(1024), 0, c->stream, bm, bitsOf[p], p, w, latW, c->latticeOwner, blockSums,
-                           c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream + region * p, c->cornerEdgeIdx, latH, c->h + c->halo);
-        blockSums += nb;
-    }
+    // 2 clears + 4 launches for the seven passes (round 1: 2 + 28): owner of every lattice point, corners per block, one scan, emission
+    hipLaunchKernelGGL(yk_corner_owner_kernel, dim3((pl.wordStart[7] * 4u + 255u) / 256u), dim3(256), 0, c->stream, pl, w, latW, c->latticeOwner);
+    hipLaunchKernelGGL(yk_corner_stream_kernel<false>, dim3((unsigned)nbTot), dim3(1024), 0, c->stream, pl, w, latW, c->latticeOwner, blockSums, perThread,
+                       c->plane[0], c->plane[1], c->plane[2], c->strideElems, (uint8_t*)nullptr, region, (uint32_t*)nullptr, latH, c->h + c->halo);
+    hipLaunchKernelGGL(yk_corner_scan_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, pl, totalDev);
+    hipLaunchKernelGGL(yk_corner_stream_kernel<true>, dim3((unsigned)nbTot), dim3(1024), 0, c->stream, pl, w, latW, c->latticeOwner, blockSums, perThread,
+                       c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream, region, c->cornerEdgeIdx, latH, c->h + c->halo);
     YK_HIP(c, hipGetLastError());
     { int rc = yk_stage_end(c, YK_STAGE_CORNERS); if (rc) return rc; }
     uint32_t totals[7];

@@ -230,22 +230,51 @@ __global__ __launch_bounds__(256) void yk_dec44p_render_kernel(const uint32_t* _
 }
 
 // ---- 1-D range decode -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
-                                                              uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix) {
-    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    if (i >= T8) return;
+// quadrant mask of tile i (bit set = quadrant already filled by a gradient tile, YAIK_3DTile.cpp:74-78); 0xF past the end
+__device__ __forceinline__ int yk_d1_quads(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8, size_t i) {
+    if (i >= T8) return 0xF;
     const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
-    int q = tile4[(tx >> 1) + (size_t)ty * stride4];
-    q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;                                        // YAIK_3DTile.cpp:74-78
-    cntTiles[i] = q != 0xF;
-    cntPix[i] = 16u * (4u - (uint32_t)__popc(q));
+    const int q = tile4[(tx >> 1) + (size_t)ty * stride4];
+    return (q >> ((tx & 1) ? 4 : 0)) & 0xF;
+}
+// coded tiles (low 11 bits) and pixel bytes (above) of a tile, packed so that one scan serves both: a block of 1024 tiles holds at
+// most 1024 coded tiles and 65536 pixel bytes
+__device__ __forceinline__ uint32_t yk_d1_packed_count(int q) { return (q != 0xF ? 1u : 0u) | ((16u * (4u - (uint32_t)__popc(q))) << 11); }
+
+// per block of 1024 tiles: coded tiles and pixel bytes, from the mask alone
+__global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
+                                                              uint32_t* __restrict__ blockTiles, uint32_t* __restrict__ blockPix) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t tot;
+    yk_block_exscan(yk_d1_packed_count(yk_d1_quads(tile4, stride4, tilesW, T8, i)), s_tmp, &tot);
+    if (threadIdx.x == 0) { blockTiles[blockIdx.x] = tot & 2047u; blockPix[blockIdx.x] = tot >> 11; }
+}
+// both block-sum arrays -> exclusive prefixes in place, totals[0] = coded tiles, totals[1] = pixel bytes (one launch)
+__global__ __launch_bounds__(1024) void yk_dec1d_scan_kernel(uint32_t* __restrict__ blockTiles, uint32_t* __restrict__ blockPix, int nBlocks, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tmp[32];
+#pragma unroll 1
+    for (int a = 0; a < 2; a++) {
+        uint32_t* arr = a ? blockPix : blockTiles;
+        uint32_t base = 0;
+        for (int start = 0; start < nBlocks; start += 1024) {
+            const int i = start + threadIdx.x;
+            const uint32_t v = i < nBlocks ? arr[i] : 0u;
+            uint32_t tot;
+            const uint32_t e = yk_block_exscan(v, s_tmp, &tot);
+            if (i < nBlocks) arr[i] = base + e;
+            base += tot;
+        }
+        if (threadIdx.x == 0) totals[a] = base;
+    }
 }
 
-// One workgroup = 1024 consecutive tiles of one plane.  Phase 1: exclusive scans (thread = tile) give every tile its offset in
-// the type and pixel streams.  Phase 2: 16 lanes per tile, one lane per quadrant row (4 pixels): a 4-byte load from the pixel
-// stream, the 4 reconstructed bytes as one store into the 8x8-tiled plane — a wave writes 256 contiguous bytes.
+// One workgroup = 1024 consecutive tiles of one plane.  Phase 1: one packed exclusive scan (thread = tile) gives every tile its offset in
+// the type and pixel streams.  Phase 2: FOUR lanes per tile, one lane per pair of rows of one half of the tile.  The stream holds a
+// half's rows as [left quadrant 4 B][right quadrant 4 B] per row, absent quadrants left out (:95-124): with both quadrants present a
+// row pair is 16 contiguous, 16-byte aligned stream bytes AND 16 contiguous bytes of the 8x8-tiled plane (one load, one store per
+// lane, a wave moves 1 KB per instruction); with one quadrant it is an 8-byte load and two 4-byte stores.
 __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
-                                                        const uint32_t* __restrict__ cntTiles, const uint32_t* __restrict__ cntPix,
                                                         const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
                                                         const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
                                                         const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
@@ -259,45 +288,53 @@ __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restric
     const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
     const size_t i0 = (size_t)blockIdx.x * 1024;
     {
-        const size_t i = i0 + threadIdx.x;
+        const int q = yk_d1_quads(tile4, stride4, tilesW, T8, i0 + threadIdx.x);
         uint32_t tot;
-        const uint32_t et = yk_block_exscan(i < T8 ? cntTiles[i] : 0u, s_tmp, &tot);
-        const uint32_t ep = yk_block_exscan(i < T8 ? cntPix[i] : 0u, s_tmp, &tot);
-        int q = 0xF;
-        if (i < T8) {
-            const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
-            q = tile4[(tx >> 1) + (size_t)ty * stride4];
-            q = (q >> ((tx & 1) ? 4 : 0)) & 0xF;                                // YAIK_3DTile.cpp:74-78: bit set = quadrant already filled
-        }
-        s_offT[threadIdx.x] = baseTiles[blockIdx.x] + et; s_offP[threadIdx.x] = basePix[blockIdx.x] + ep; s_q[threadIdx.x] = (uint8_t)q;
+        const uint32_t e = yk_block_exscan(yk_d1_packed_count(q), s_tmp, &tot);
+        s_offT[threadIdx.x] = baseTiles[blockIdx.x] + (e & 2047u); s_offP[threadIdx.x] = basePix[blockIdx.x] + (e >> 11); s_q[threadIdx.x] = (uint8_t)q;
     }
     __syncthreads();
-    const int l16 = threadIdx.x & 15, half = l16 >> 3, r = (l16 >> 1) & 3, side = l16 & 1;
-    for (int it = 0; it < 16; it++) {
-        const int t = it * 64 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 3, half = j >> 1, rp = j & 1;
+    uint8_t* const plane = planes + (size_t)p * planeSize;
+#pragma unroll 1
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 256 + (threadIdx.x >> 2);
         const size_t i = i0 + t;
         if (i >= T8) break;
         const int q = s_q[t];
-        if (q == 0xF) continue;
-        const bool present = !((q >> (half * 2 + side)) & 1);
-        if (!present) continue;
-        const int nTop = 2 - (q & 1) - ((q >> 1) & 1), nBot = 2 - ((q >> 2) & 1) - ((q >> 3) & 1);
-        const bool leftPresent = !((q >> (half * 2)) & 1);
-        // stream order: half 0 rows (left then right quadrant of each row), then half 1 (:95-124)
-        const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)r * 4 * (half ? nBot : nTop) + ((side && leftPresent) ? 4 : 0);
+        const int qh = (q >> (half * 2)) & 3;                                    // bit 0: left quadrant filled, bit 1: right
+        if (qh == 3) continue;
+        const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
         const size_t to = (baseT + s_offT[t]) * 3;
         if (to + 2 >= typeBytes) continue;
         const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
-        const uint32_t L4 = (po + 3 < pixBytes) ? *reinterpret_cast<const uint32_t*>(pix + po) : 0u;      // po is a multiple of 4
-        uint32_t out = 0;
+        auto dec4 = [&](uint32_t L4) {
+            uint32_t out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int L = (L4 >> (8 * k)) & 255;
-            const int v = L ? (base + (((L - 1) * delta2) >> 16)) : color0;     // :113-124
-            out |= (uint32_t)(v & 255) << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                const int L = (L4 >> (8 * k)) & 255;
+                const int v = L ? (base + (((L - 1) * delta2) >> 16)) : color0;     // :113-124
+                out |= (uint32_t)(v & 255) << (8 * k);
+            }
+            return out;
+        };
+        uint8_t* const o = plane + i * 64 + (half * 4 + rp * 2) * 8;               // the lane's two rows: 16 contiguous bytes of the tile
+        if (qh == 0) {
+            const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)rp * 16;
+            uint4 L = make_uint4(0u, 0u, 0u, 0u);
+            if (po + 16 <= pixBytes) L = *reinterpret_cast<const uint4*>(pix + po);
+            else if (po < pixBytes) { uint32_t tmp[4] = { 0, 0, 0, 0 }; for (int k = 0; k < 4; k++) if (po + 4 * k + 3 < pixBytes) tmp[k] = *reinterpret_cast<const uint32_t*>(pix + po + 4 * k); L = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]); }
+            *reinterpret_cast<uint4*>(o) = make_uint4(dec4(L.x), dec4(L.y), dec4(L.z), dec4(L.w));
+        } else {
+            const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)rp * 8;
+            uint2 L = make_uint2(0u, 0u);
+            if (po + 8 <= pixBytes) L = *reinterpret_cast<const uint2*>(pix + po);
+            else if (po + 3 < pixBytes) L.x = *reinterpret_cast<const uint32_t*>(pix + po);
+            const int side = qh & 1;                                             // left filled -> the present quadrant is the right one
+            *reinterpret_cast<uint32_t*>(o + side * 4) = dec4(L.x);
+            *reinterpret_cast<uint32_t*>(o + 8 + side * 4) = dec4(L.y);
         }
-        *reinterpret_cast<uint32_t*>(planes + (size_t)p * planeSize + i * 64 + (half * 4 + r) * 8 + side * 4) = out;
     }
 }
 
@@ -491,24 +528,20 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
     YK_HIP(c, hipSetDevice(c->device));
     const int w = c->dw, h = c->dh, tilesW = w >> 3;
     const size_t T8 = (size_t)tilesW * (h >> 3), nb = (T8 + 1023) / 1024;
-    const size_t oTy = 0, oPx = (oTy + typeBytes + 31) & ~(size_t)15, oCT = (oPx + pixBytes + 31) & ~(size_t)15, oCP = oCT + T8 * 4,
-                 oBT = oCP + T8 * 4, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16;
+    const size_t oTy = 0, oPx = (oTy + typeBytes + 31) & ~(size_t)15, oCT = (oPx + pixBytes + 31) & ~(size_t)15, oCP = oCT + 16,
+                 oBT = oCP + 16, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16;
     int rc = yk_dec_scratch(c, oTot + 64); if (rc) return rc;
     uint8_t* S = c->dScratch;
     YK_HIP(c, hipMemcpyAsync(S + oTy, typeStream, typeBytes, hipMemcpyHostToDevice, c->stream));
     YK_HIP(c, hipMemcpyAsync(S + oPx, pixStream, pixBytes, hipMemcpyHostToDevice, c->stream));
-    uint32_t* cT = reinterpret_cast<uint32_t*>(S + oCT); uint32_t* cP = reinterpret_cast<uint32_t*>(S + oCP);
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     if (!c->dSplit) {
-        // no partial-plane pass ran: the three planes share one mask, one count / scan serves all of them
-        hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP);
-        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
-        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
-        hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
+        // no partial-plane pass ran: the three planes share one mask, one count / scan serves all of them (3 launches)
+        hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP);
+        hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
+        hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
                            S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, -1, (const uint32_t*)nullptr);
     } else {
         // per-plane masks (Decompress1D reads tile4x4Mask + planeID * tile4x4MaskSize, YAIK_3DTile.cpp:41): one plane after the other,
@@ -517,12 +550,9 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
         YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
         for (int p = 0; p < 3; p++) {
             const uint8_t* t4 = c->dTile4 + (size_t)p * c->dTile4Size;
-            hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, cT, cP);
-            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
-            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
-            hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
-            hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
-            hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, cT, cP, bT, bP, tot,
+            hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP);
+            hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
+            hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
                                S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, p, (const uint32_t*)runBase);
             hipLaunchKernelGGL(yk_dec1d_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
         }
