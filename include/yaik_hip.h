@@ -252,9 +252,13 @@ int yk_selftest(yk_ctx* c, int which, int* result);
  * One flag only selects a code path and leaves the results exact (used by the parity tests): 16 = re-sum every tile in the
  * reference's sequential order. */
 int yk_set_ablation(yk_ctx* c, int flags);
-/* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = lane per 4x4 cell, 1 = lane per pixel row.
- * Both produce identical results; kept selectable for A/B timing and as a cross-check in the tests. */
+/* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = the library's kernel (lane per 4x4 cell); 1 = an
+ * external cross-check implementation registered with yk_set_cross_check_launcher (the test suite's first-generation kernel,
+ * tests/csrc/yk_encode_v1.hip: lane per pixel row).  Without a registered launcher version 1 fails with YK_ERR_STATE at encode time. */
 int yk_set_kernel_version(yk_ctx* c, int version);
+/* test hook: fn = int (*)(hipStream_t stream, const YkEncodeParams* params) (yaik_amd/csrc/yk_common.h), launching a kernel that fills the
+ * same per-tile outputs from the same parameters; NULL unregisters.  Process-wide. */
+int yk_set_cross_check_launcher(void* fn);
 
 /* ---- timing hooks for bench.py: HIP events on the handle's stream around every alpha stage / fused kernel / compaction.
  * Returns the averages over the yk_encode_tiles calls since the previous query (a ring of 64 event sets, older ones are

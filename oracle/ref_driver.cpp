@@ -20,7 +20,11 @@
 // running the reference's own PaletteDecompressor on that output, exactly as the decoder does, which
 // yields the de-quantised bytes the gradient decode loops consume.  No reference code is copied or altered.
 //
-// usage: ref_driver <in.bin> <out.blobs> [partial]
+// usage: ref_driver <in.bin> <out.blobs> [partial | lut3d <bank.bin>]
+//   lut3d   : (f)4.  After the seven RGB passes: Load3DPattern for every pattern of a SYNTHETIC bank (bank.bin = the patterns in the file
+//             format Load3DPattern reads, EncoderContext.cpp:7851-7867: u8 count, count x r, count x g, count x b, 6-bit values; written
+//             one file per pattern into the scratch directory), StartCorrelationSearch, Correlation3DSearch x6 in Convert()'s order
+//             (:9139-9199), EndCorrelationSearch (the '3DTL' chunk); blobs lut_*.  The reference's own 22-file bank is not in its repo.
 //   partial : after the seven RGB passes also run the six partial-plane 4x4 passes in the order the reference's Convert() lists them
 //             (RB, RG, GB, R, G, B; EncoderContext.cpp:9261-9415, disabled there by `if (0)` / `#if 0`), before the 1-D path, and
 //             decode them with DecompressGradient4x4(planeBit) (blobs pp_*)
@@ -41,6 +45,7 @@
 
 // ---- reference symbols that no header declares (EncoderContext.cpp:702, :8217-8218)
 void DynamicTileEncoderTable();
+int BitmapSwizzleMapSize(int TshiftX, int TshiftY, int imgW, int imgH);         // EncoderContext.cpp:7310
 extern u8* streamType;
 extern u8* pType;
 
@@ -100,6 +105,14 @@ static std::string nm(const char* base, int a, int b = -1) {
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: ref_driver in.bin out.blobs [partial]\n"); return 2; }
     const bool partial = argc > 3 && !strcmp(argv[3], "partial");
+    const bool lut3d = argc > 4 && !strcmp(argv[3], "lut3d");
+    std::vector<u8> bankBytes;
+    if (lut3d) {
+        FILE* fb = fopen(argv[4], "rb"); if (!fb) { perror("bank"); return 2; }
+        u8 tmp[4096]; size_t n;
+        while ((n = fread(tmp, 1, sizeof tmp, fb)) > 0) bankBytes.insert(bankBytes.end(), tmp, tmp + n);
+        fclose(fb);
+    }
     FILE* fi = fopen(argv[1], "rb");
     if (!fi) { perror("in"); return 2; }
     int hdr[3];
@@ -217,6 +230,70 @@ int main(int argc, char** argv) {
     }
 
     blob("stage_seconds", stage, sizeof stage);
+
+    // ---- (f)4 3D-LUT tiles: Load3DPattern (:7851), Set3DPointCloud (:4744), Correlation3DSearch (:6245) with computeValues3D (:5807),
+    // EndCorrelationSearch (:7366).  Runs where Convert() runs it: after the gradient passes, before the 1-D compressor.
+    if (lut3d) {
+        int nPat = 0;
+        for (size_t off = 0; off < bankBytes.size(); nPat++) {
+            const size_t len = 1 + 3 * (size_t)bankBytes[off];
+            char name[64]; snprintf(name, sizeof name, "pattern_%02d.lut", nPat);
+            FILE* fp = fopen(name, "wb"); if (!fp) return 2;
+            fwrite(&bankBytes[off], 1, len, fp); fclose(fp);
+            ctx->Load3DPattern(name);
+            off += len;
+        }
+        if (ctx->correlationPatternCount3D != nPat) return 4;
+        for (int e = 0; e < nPat; e++) {                                  // the tables Set3DPointCloud built
+            EncoderContext::EvalCtx3D& ev = ctx->correlationPattern3D[e];
+            s16 f[(64 + 32 + 16 + 8) * 3];
+            memcpy(f, ev.xFactor6Bit, 128); memcpy(f + 64, ev.yFactor6Bit, 128); memcpy(f + 128, ev.zFactor6Bit, 128);
+            memcpy(f + 192, ev.xFactor5Bit, 64); memcpy(f + 224, ev.yFactor5Bit, 64); memcpy(f + 256, ev.zFactor5Bit, 64);
+            memcpy(f + 288, ev.xFactor4Bit, 32); memcpy(f + 304, ev.yFactor4Bit, 32); memcpy(f + 320, ev.zFactor4Bit, 32);
+            memcpy(f + 336, ev.xFactor3Bit, 16); memcpy(f + 344, ev.yFactor3Bit, 16); memcpy(f + 352, ev.zFactor3Bit, 16);
+            blob(nm("lut_factors", e), f, sizeof f);
+            blob(nm("lut_distanceField", e), ev.distanceField3D, sizeof ev.distanceField3D);
+            std::vector<u8> pos(4 * 64 * 64 * 64);
+            for (int i = 0; i < 64 * 64 * 64; i++) {
+                pos[i] = (u8)ev.position6Bit3D[i]; pos[262144 + i] = (u8)ev.position5Bit3D[i];
+                pos[2 * 262144 + i] = (u8)ev.position4Bit3D[i]; pos[3 * 262144 + i] = (u8)ev.position3Bit3D[i];
+            }
+            blob(nm("lut_positions", e), pos.data(), pos.size());
+        }
+        ctx->pStats = new EncoderStats();                                 // EndCorrelationSearch adds to it unconditionally (:7622)
+        ctx->useYCoCg = false; ctx->isCaptureMode3D = false; ctx->testedLUT = nPat;
+        ctx->StartCorrelationSearch(true);
+        static const int lutPass[6][2] = { {4,3}, {3,4}, {3,3}, {3,2}, {2,3}, {2,2} };       // :9144-9199
+        int cnt[6][6];
+        for (int i = 0; i < 6; i++) {
+            ctx->Correlation3DSearch(img, preview, lutPass[i][0], lutPass[i][1]);
+            const int c6[6] = { ctx->streamTypeCnt, ctx->streamColorCnt, ctx->stream3BitCnt, ctx->stream4BitCnt, ctx->stream5BitCnt, ctx->stream6BitCnt };
+            memcpy(cnt[i], c6, sizeof c6);
+        }
+        blob("lut_counts", cnt, sizeof cnt);                             // cumulative after each pass: tiles, colour bytes, 3/4/5/6-bit indices
+        blob("lut_tileType", ctx->corr3D_tileStreamTileType, (size_t)ctx->streamTypeCnt * 2);
+        blob("lut_color", ctx->corr3D_colorStream, ctx->streamColorCnt);
+        blob("lut_idx3", ctx->corr3D_stream3Bit, ctx->stream3BitCnt);
+        blob("lut_idx4", ctx->corr3D_stream4Bit, ctx->stream4BitCnt);
+        blob("lut_idx5", ctx->corr3D_stream5Bit, ctx->stream5BitCnt);
+        blob("lut_idx6", ctx->corr3D_stream6Bit, ctx->stream6BitCnt);
+        u8* maps[6] = { ctx->corr3D_sizeT16_8Map, ctx->corr3D_sizeT8_16Map, ctx->corr3D_sizeT8_8Map, ctx->corr3D_sizeT8_4Map, ctx->corr3D_sizeT4_8Map, ctx->corr3D_sizeT4_4Map };
+        for (int i = 0; i < 6; i++) blob(nm("lut_map", i), maps[i], BitmapSwizzleMapSize(lutPass[i][0], lutPass[i][1], w, h));
+        for (int p = 0; p < 3; p++) blobPlane8(nm("lut_mapSmoothTile", p), ctx->mapSmoothTile->GetPlane(p));
+        for (int p = 0; p < 3; p++) blobPlane16(nm("lut_preview", p), preview->GetPlane(p));
+        gZstd.clear();
+        fflush(ctx->outFile);
+        const long before = ftell(ctx->outFile);
+        ctx->EndCorrelationSearch(true, 7);                               // '3DTL' chunk: 6 maps, tile types, colours (CompressF), index streams (x3)
+        fflush(ctx->outFile);
+        const long after = ftell(ctx->outFile);
+        std::vector<u8> chunk((size_t)(after - before));
+        fseek(ctx->outFile, before, SEEK_SET);
+        if (!chunk.empty() && fread(chunk.data(), 1, chunk.size(), ctx->outFile) != chunk.size()) return 2;
+        fseek(ctx->outFile, after, SEEK_SET);
+        blob("lut_chunk_header", chunk.data(), chunk.size() < 8 + sizeof(HeaderTile3D) ? chunk.size() : 8 + sizeof(HeaderTile3D));
+        for (size_t k = 0; k < gZstd.size(); k++) blob(nm("lut_zin", (int)k), gZstd[k].data.data(), gZstd[k].data.size());
+    }
 
     // ---- a6 with nullable planes: the partial-plane 4x4 passes (PlaneBit :3715, per-plane allow :3871-3875, per-plane paint :4031-4034)
     static const int ppMask[6] = { 5, 3, 6, 1, 2, 4 };                  // RB, RG, GB, R, G, B

@@ -31,7 +31,7 @@ def parse_blobs(path: str) -> dict[str, bytes]:
     return out
 
 
-def run_reference(planes: np.ndarray, partial: bool = False) -> dict[str, bytes]:
+def run_reference(planes: np.ndarray, partial: bool = False, lut_bank: bytes | None = None) -> dict[str, bytes]:
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     n, h, w = planes.shape
     with tempfile.TemporaryDirectory() as d:
@@ -40,5 +40,11 @@ def run_reference(planes: np.ndarray, partial: bool = False) -> dict[str, bytes]
         with open(fin, "wb") as f:
             f.write(struct.pack("<3i", w, h, n))
             f.write(planes.tobytes())
-        subprocess.run([REF_DRIVER, fin, fout] + (["partial"] if partial else []), check=True, stdout=subprocess.DEVNULL)
+        extra = ["partial"] if partial else []
+        if lut_bank is not None:                                      # (f)4: a synthetic 3-D LUT bank in Load3DPattern's file format
+            fbank = os.path.join(d, "bank.bin")
+            with open(fbank, "wb") as f:
+                f.write(lut_bank)
+            extra = ["lut3d", fbank]
+        subprocess.run([REF_DRIVER, fin, fout] + extra, check=True, stdout=subprocess.DEVNULL)
         return parse_blobs(fout)

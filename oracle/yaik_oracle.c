@@ -9,29 +9,7 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------- */
-struct yko_enc {
-    int w, h, nPlanes;
-    int32_t* plane[4];
-    /* EncoderContext state (EncoderContext.h:273-323), kept as bytes 0/255 */
-    uint8_t* mipmapMask;            /* NULL until CheckMipmapMask / MipPrefilter */
-    uint8_t* smoothMap;             /* NULL until first FittingQuadSmooth (:3739) */
-    uint8_t* mapSmoothTile[3];
-    uint8_t* mappedRGB[3];          /* (w+1)*(h+1) */
-    int32_t* preview[3];
-    int boundX0, boundY0, boundX1, boundY1, mipMapTileSize, remainingPixels;
-    int tileBBox[4];
-    uint8_t* mipBitmap; int mipBitmapBytes;
-    uint8_t* lastBitmap; int lastBitmapBytes;
-    uint8_t* lastRgb; int lastRgbBytes;
-    uint16_t* tileDefs; int nDefs;
-    uint8_t* nibbles; int nNibbles;
-    uint8_t* pix1d; int nPix1d; size_t capPix1d;
-    uint8_t* type1d; int nType1d; size_t capType1d;
-    /* PaletteCompressor's process-global code table CodeRGB/CodeCount (EncoderContext.cpp:3216-3217): only the
-     * count is reset per call, stale rows stay and are still matched by FindCodeBook (:3248-3255). */
-    int (*codeRGB)[4]; int codeCount, codeCap;   /* ref, dr, dg, db */
-    uint8_t* lastPalette; int lastPaletteBytes;
-};
+#include "yaik_oracle_internal.h"
 
 yko_enc* yko_enc_create(int w, int h, int nPlanes, const int32_t* const* planes) {
     if (w <= 0 || h <= 0 || nPlanes < 3 || nPlanes > 4) return NULL;
@@ -51,6 +29,7 @@ void yko_enc_destroy(yko_enc* e) {
     for (int p = 0; p < 3; p++) { free(e->mapSmoothTile[p]); free(e->mappedRGB[p]); free(e->preview[p]); }
     free(e->mipBitmap); free(e->lastBitmap); free(e->lastRgb); free(e->tileDefs); free(e->nibbles);
     free(e->pix1d); free(e->type1d); free(e->codeRGB); free(e->lastPalette);
+    yko_lut_free(e->lut);
     free(e);
 }
 

@@ -1,0 +1,67 @@
+"""A SYNTHETIC 3-D LUT bank for (f)4, in the file format the reference's Load3DPattern reads (EncoderContext.cpp:7851-7867):
+u8 count, then count x r, count x g, count x b, every value 6 bits (a point of the 64^3 cube the tile colours are normalised into).
+The reference's own bank (22 'Bank3D//*.lut' files, :7796-7819) is not in its repository; this generator lets the reference, the oracle and
+the HIP path run the same search.  Patterns hold at most 64 points: beyond that Load3DPattern reduces the array to 64 entries but still
+hands Set3DPointCloud the original count (:7907-7917), which reads and writes past its 64-entry tables."""
+import numpy as np
+
+
+def bank_patterns(n_patterns: int = 6) -> list:
+    """List of uint8 arrays [count, 3] (r, g, b in 0..63)."""
+    i = np.arange(64, dtype=np.float64)
+    t = i / 63.0
+    pats = [
+        np.stack([i, i, i], 1),                                                    # the diagonal: colours between two end points
+        np.stack([i, 63 * t * t, i], 1),                                           # one channel lags
+        np.stack([i, 63 * np.sqrt(t), 63 * t * t], 1),                             # one leads, one lags
+        np.stack([i, np.minimum(2 * i, 63), np.maximum(2 * i - 63, 0)], 1),        # a bent path through a cube edge
+        np.stack([63 * (1 - np.cos(np.pi * t)) / 2, i, 63 - i], 1),                # S-curve against a falling channel
+        np.stack([i[:40] * 63 / 39, 63 - i[:40] * 63 / 39, i[:40] * 63 / 39 * 0.5], 1),   # 40 points only
+    ]
+    return [np.clip(np.floor(p + 0.5), 0, 63).astype(np.uint8) for p in pats[:n_patterns]]
+
+
+def bank_bytes(patterns) -> bytes:
+    out = bytearray()
+    for p in patterns:
+        out.append(len(p))
+        out += p[:, 0].tobytes() + p[:, 1].tobytes() + p[:, 2].tobytes()
+    return bytes(out)
+
+
+def lut_image(w: int, h: int, patterns=None, seed: int = 3) -> np.ndarray:
+    """int32 planes [3, h, w]: 16x16 blocks whose colours run along a bank pattern between two random end colours with a non-bilinear
+    parameter field (the gradient passes reject them, the 3-D LUT search should take them), mixed with ramp blocks (gradient tiles),
+    noise blocks (nothing matches) and blocks that are flat in one channel."""
+    patterns = patterns or bank_patterns()
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    out = np.zeros((3, h, w), dtype=np.int64)
+    ramp = np.stack([(x * 255) // w, (y * 255) // h, ((x + y) * 255) // (w + h)])
+    for by in range(0, h, 16):
+        for bx in range(0, w, 16):
+            sl = (slice(None), slice(by, min(by + 16, h)), slice(bx, min(bx + 16, w)))
+            kind = rng.integers(0, 8)
+            yy, xx = y[sl[1:]] - by, x[sl[1:]] - bx
+            if kind == 0:
+                out[sl] = ramp[sl]
+            elif kind == 1:
+                out[sl] = rng.integers(0, 256, out[sl].shape)
+            else:
+                e = int(rng.integers(0, len(patterns)))
+                pts = patterns[e].astype(np.float64) / 63.0
+                c0 = rng.integers(0, 200, 3).astype(np.float64)
+                c1 = c0 + rng.integers(20, 56, 3)
+                if kind == 2:
+                    c1[int(rng.integers(0, 3))] = c0[int(rng.integers(0, 3))]                # sometimes flat in a channel
+                field = ((xx * 5 + yy * 3 + (xx * yy) // 3) % 23) / 22.0                      # not bilinear
+                if rng.integers(0, 2):
+                    field = np.sqrt(((xx - 7.5) ** 2 + (yy - 7.5) ** 2) / 112.5)
+                idx = np.clip(np.floor(field * (len(pts) - 1) + 0.5), 0, len(pts) - 1).astype(np.int64)
+                flip = rng.integers(0, 2, 3)
+                for c in range(3):
+                    v = pts[idx, c]
+                    if flip[c]:
+                        v = 1.0 - v
+                    out[c][sl[1:]] = np.floor(c0[c] + v * (c1[c] - c0[c]) + 0.5)
+    return np.ascontiguousarray(np.clip(out, 0, 255).astype(np.int32))

@@ -53,3 +53,17 @@ def compare_encode(planes: np.ndarray, hip, mode3bit_only: bool, want_dst: bool 
         if want_dst:
             chk(f"range.dst{p}", hip.range_dst(p), dst)
     return bad
+
+
+def select_kernel_version(enc, version: int) -> None:
+    """version 2 = the library's fused kernel; 1 = the test suite's independent first-generation implementation
+    (tests/csrc/libyaik_v1check.so, built by yaik_amd/csrc/Makefile), handed to the library through its cross-check hook."""
+    import ctypes as C
+    import os
+    from yaik_amd._lib import lib
+    if version == 1:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libyaik_v1check.so")
+        v1 = C.CDLL(path)
+        select_kernel_version._keep = v1                                   # the library keeps a raw function pointer
+        assert lib().yk_set_cross_check_launcher(C.cast(v1.yk_v1_launch, C.c_void_p)) == 0
+    assert lib().yk_set_kernel_version(enc._h, version) == 0

@@ -70,7 +70,8 @@ def hip(request):
     from yaik_amd._lib import lib
     from yaik_amd.encoder import HipTileEncoder
     e = HipTileEncoder(0)
-    assert lib().yk_set_kernel_version(e._h, request.param) == 0
+    from tests.parity import select_kernel_version
+    select_kernel_version(e, request.param)
     yield e
     e.close()
 

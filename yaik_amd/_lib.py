@@ -96,6 +96,7 @@ SIGNATURES = {
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
     "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),
+    "yk_set_cross_check_launcher": (C.c_int, [vp]),
     "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 

@@ -1,5 +1,5 @@
 // yk_api.hip — the C-ABI of include/yaik_hip.h: handle lifetime, HBM buffers, launch order, result getters.
-// Host-side glue only; every pixel is touched by the kernels in yk_encode.hip / yk_corners.hip / yk_decode.hip.
+// Host-side glue only; every pixel is touched by the kernels in yk_stages.hip / yk_encode2.hip / yk_corners.hip / yk_partial.hip / yk_range1d.hip / yk_decode.hip.
 #include "yk_common.h"
 #include <cstdio>
 #include <cstring>

@@ -129,7 +129,7 @@ struct yk_ctx {
     // (planes, shape, arguments) and replayed with one launch — for batches of small frames, where launches dominate
     hipGraphExec_t frameGraph = nullptr;
     unsigned long long frameGraphKey[12] = {};
-    int kernelVersion = 2;              // 1 = yk_encode_kernel (lane = pixel row), 2 = yk_encode2_kernel (lane = 4x4 cell)
+    int kernelVersion = 2;              // 2 = yk_encode2_kernel; 1 = the registered cross-check launcher (tests/csrc/yk_encode_v1.hip)
 };
 
 int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e = hipSuccess);

@@ -1,4 +1,4 @@
-// yk_encode2.hip — second-generation fused kernel (same results as yk_encode_kernel, different work decomposition).
+// yk_encode2.hip — second-generation fused kernel (same results as the first-generation yk_encode_kernel of tests/csrc/yk_encode_v1.hip, different work decomposition).
 //
 //   a6       7x EncoderContext::FittingQuadSmooth            (encoder/EncoderContext.cpp:3710-4363)
 //   a10-a13  DynamicTileEncode / GetMinMax_Y / GetTileDynamic_Y / DynamicTile::buildTable
@@ -42,7 +42,7 @@ __device__ __forceinline__ float y2_lane_xor4(float v) { return __int_as_float(y
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
-// One gradient pass for the four macro-tiles of a wave.  Arithmetic identical to yk_grad_pass (see yk_encode.hip): with
+// One gradient pass for the four macro-tiles of a wave.  Arithmetic identical to yk_grad_pass (tests/csrc/yk_encode_v1.hip): with
 // 1/16-unit weights S' = (TL*lx+TR*rx)*wy + (BL*lx+BR*rx)*wb fits 16 bits and the six variants of EncoderContext.cpp:3929-3991
 // are range tests on D = S' - 256*cur per corner set.  Here the arithmetic is PACKED: two 16-bit streams per VALU op.
 //   * streams: t = 0..2: channel t of (raw corners | Round6 corners); t = 3: Round6P corners of (channel 0 | channel 1);
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     unsigned long long cov = 0ULL;                                           // bit = lane = 4x4 cell covered
     {
         // S' is linear in x inside any tile, so |c(x-1)-2c(x)+c(x+1)| <= 4*rejectFactor+1 is necessary for acceptance of every
-        // tile containing the three pixels (see yk_encode.hip).  Row 0 of the cell is tested: six tests already leave a cell of
+        // tile containing the three pixels (see tests/csrc/yk_encode_v1.hip).  Row 0 of the cell is tested: six tests already leave a cell of
         // noise alive with probability < 1e-7, a second row only costs the other content instructions.
         bool dead = !mtIn;
         {
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const int BN = (base * 224) / 63;
             const int d8 = max(diff, 32);
             const int scale = 223 - BN;
-            const int dnum = (d8 - 32) * 127 + (scale - 1);                  // see yk_encode.hip / yk_selftest 1
+            const int dnum = (d8 - 32) * 127 + (scale - 1);                  // see tests/csrc/yk_encode_v1.hip / yk_selftest 1
             const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
             const int rangeDecode = (dist * scale) / 127 + 32;
             // The tile's six LUTs (4-bit: 16 entries + three quarter midpoints, 3-bit: 8 entries; stored << 8) in LDS.  Only the

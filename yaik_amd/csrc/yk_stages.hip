@@ -1,0 +1,297 @@
+// yk_stages.hip — the kernels around the fused encode kernel (yk_encode2.hip) and the stage launchers.
+//
+//   yk_alpha_kernel        a9   EncoderContext::MipPrefilter / quadRecursion   (encoder/EncoderContext.cpp:357-430, 1257-1427)
+//   yk_scan*/yk_pack       stream compaction of the per-tile results into the reference's global streams
+//                          (`streamTileDef` :4419, `streamTileIdx` :4421, nibble packing :1180-1184)
+// The first-generation fused kernel (yk_encode_kernel: lane = one row of four pixels) is no longer part of this library: it lives in
+// tests/csrc/yk_encode_v1.hip as an independent second implementation the parity tests cross-check against (yk_set_cross_check_launcher).
+//
+// No MFMA: integer / byte work bounded by HBM streaming.
+#include "yk_common.h"
+#include "yk_device.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// a9: alpha tile-reject, stage 1.  keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed
+// form of quadRecursion with maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (:416-422).
+//
+// The plane is streamed in memory order like a reduction: a work unit is (row, 4096-pixel segment), every lane has four
+// 16-byte loads in flight and a wave instruction covers 1 KB of one row.  Four adjacent lanes hold the 16 pixels of one
+// tile row; a non-zero group raises the tile's flag with an idempotent byte store into the pre-zeroed map, so the
+// streaming path has no atomics.  The bounding box is derived from the flags afterwards (yk_alpha_bbox_kernel).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h,
+                                                       uint8_t* __restrict__ keep0, int mtW, int32_t* __restrict__ bounds,
+                                                       int nFrames, unsigned long long planeStride, unsigned long long keepStride) {
+    // accumulators of the bounding-box kernel that follows on the stream: {x0,y0,x1,y1} = empty, done-counter = 0 (one set per frame)
+    for (int f = blockIdx.x; f < nFrames; f += gridDim.x)
+        if (threadIdx.x < 5) bounds[(size_t)f * 16 + 8 + threadIdx.x] = threadIdx.x < 2 ? 9999999 : (threadIdx.x < 4 ? -1 : 0);
+    const int lane = threadIdx.x & 63;
+    const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
+    const int nSeg = (vecPerRow + 1023) >> 10;
+    const int nUnits = nSeg * h;
+    for (long long uu = blockIdx.x; uu < (long long)nUnits * nFrames; uu += gridDim.x) {
+        const int f = (int)(uu / nUnits), u = (int)(uu - (long long)f * nUnits);
+        const int32_t* alpha = alpha0 + (size_t)f * planeStride;
+        uint8_t* keep = keep0 + (size_t)f * keepStride;
+        const int y = u / nSeg, seg = u - y * nSeg;
+        const int32_t* row = alpha + (size_t)y * strideElems;
+        int4 a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xv = seg * 1024 + k * 256 + threadIdx.x;
+            a[k] = make_int4(0, 0, 0, 0);
+            if (xv < vecPerRow) a[k] = *reinterpret_cast<const int4*>(row + xv * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xv = seg * 1024 + k * 256 + threadIdx.x;
+            const unsigned long long b = __ballot((a[k].x | a[k].y | a[k].z | a[k].w) != 0);
+            if ((lane & 3) == 0 && ((b >> lane) & 0xFULL) != 0) keep[(size_t)(y >> 4) * mtW + (xv >> 2)] = 1;
+        }
+    }
+}
+
+// bounding box of the kept 16x16 tiles (quadRecursion's boundingL/T/R/B, EncoderContext.cpp:416-422) from the keep flags;
+// one atomic per workgroup and bound (a single address only sustains ~88 atomics/us).  The last workgroup to finish also
+// publishes the whole-image form: bounds[0..3] = the box, bounds[4] = "bbox == whole image -> every reject discarded"
+// (EncoderContext.cpp:1294, :1400-1403); a stripe caller overrides these five ints with the host-combined box.
+__global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint32_t* __restrict__ keep4, int mtW, int mtH, int y0, int32_t* __restrict__ bounds,
+                                                            int fullW, int fullH, unsigned long long keepStrideWords) {
+    __shared__ int s_red[4][4];
+    keep4 += (size_t)blockIdx.y * keepStrideWords;               // blockIdx.y = frame of a batch
+    bounds += (size_t)blockIdx.y * 16;
+    int32_t* bbox = bounds + 8;
+    int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
+    const int n = mtW * mtH, n4 = (n + 3) >> 2;                  // four 1-byte flags per load (the map is padded to a multiple of 4)
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+        uint32_t f = keep4[i4];
+        if (!f) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i4 * 4 + k;
+            if (((f >> (8 * k)) & 255u) && i < n) {
+                const int my = i / mtW, mx = i - my * mtW;
+                x0 = min(x0, mx * 16); x1 = max(x1, mx * 16 + 16);
+                gy0 = min(gy0, y0 + my * 16); gy1 = max(gy1, y0 + my * 16 + 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        x0 = min(x0, __shfl_xor(x0, d)); x1 = max(x1, __shfl_xor(x1, d));
+        gy0 = min(gy0, __shfl_xor(gy0, d)); gy1 = max(gy1, __shfl_xor(gy1, d));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[wave][0] = x0; s_red[wave][1] = gy0; s_red[wave][2] = x1; s_red[wave][3] = gy1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            x0 = min(x0, s_red[k][0]); gy0 = min(gy0, s_red[k][1]); x1 = max(x1, s_red[k][2]); gy1 = max(gy1, s_red[k][3]);
+        }
+        if (x1 >= 0) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], gy0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], gy1); }
+        __threadfence();
+        if (atomicAdd(&bbox[4], 1) == (int)gridDim.x - 1) {       // every other workgroup's atomics are visible now
+            const int bx0 = atomicAdd(&bbox[0], 0), by0 = atomicAdd(&bbox[1], 0), bx1 = atomicAdd(&bbox[2], 0), by1 = atomicAdd(&bbox[3], 0);
+            bounds[0] = bx0; bounds[1] = by0; bounds[2] = bx1; bounds[3] = by1;
+            bounds[4] = (bx0 == 0 && by0 == 0 && bx1 == fullW && by1 == fullH) ? 1 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stream compaction: per-tile (count, def, 32-byte nibble slot) -> the reference's global streams, LeftRightOrder =
+// row-major over the tile grid (tiles outside the constraint box carry count 0).
+// ------------------------------------------------------------------------------------------------------------------
+#define YK_SCAN_TILE 1024
+
+// first scan level for the first-generation kernel (the second-generation kernel accumulates these sums itself)
+__global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restrict__ tileCount, size_t T8, uint32_t* __restrict__ blockCnt) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t i = (size_t)blockIdx.x * YK_SCAN_TILE + threadIdx.x;
+    const uint32_t c = (i < T8) ? tileCount[i] : 0;                          // plane 0: the counts do not depend on the plane
+    uint32_t tot2, totN;
+    yk_block_exscan(c ? 1u : 0u, s_tmp, &tot2);
+    yk_block_exscan(c, s_tmp, &totN);
+    if (threadIdx.x == 0) { blockCnt[(size_t)blockIdx.x * 2] = totN; blockCnt[(size_t)blockIdx.x * 2 + 1] = tot2; }
+}
+
+// second level: exclusive prefix over the per-block sums (consumed and cleared for the next frame) and the totals of the
+// three planes (identical: the counts do not depend on the plane).
+__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
+                                                        uint32_t* __restrict__ totals, unsigned long long blockNStride) {
+    __shared__ uint32_t s_tmp[32];
+    blockCnt += (size_t)blockIdx.x * blockNStride; blockSums += (size_t)blockIdx.x * blockNStride;     // blockIdx.x = frame of a batch
+    totals += (size_t)blockIdx.x * 8;
+    uint32_t baseN = 0, baseD = 0;
+    for (int start = 0; start < nBlocks; start += 1024) {
+        const int i = start + threadIdx.x;
+        const uint32_t n = i < nBlocks ? blockCnt[i * 2] : 0, d = i < nBlocks ? blockCnt[i * 2 + 1] : 0;
+        uint32_t totN, totD;
+        const uint32_t en = yk_block_exscan(n, s_tmp, &totN);
+        const uint32_t ed = yk_block_exscan(d, s_tmp, &totD);
+        if (i < nBlocks) {
+            blockSums[i * 2] = baseN + en; blockSums[i * 2 + 1] = baseD + ed;
+            blockCnt[i * 2] = 0; blockCnt[i * 2 + 1] = 0;
+        }
+        baseN += totN; baseD += totD;
+    }
+    if (threadIdx.x < 3) { totals[threadIdx.x * 2] = baseD; totals[threadIdx.x * 2 + 1] = baseN; }
+}
+
+// One workgroup packs the nibbles of 1024 consecutive tiles.  Every tile holds a multiple of 16 nibbles (16 per uncovered 4x4
+// quadrant), so every stream offset is a multiple of 8 bytes: after the scan, four lanes per tile copy 8-byte pieces of the
+// tile's slot straight to its place in the stream, reading only the bytes that exist.
+__global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
+                                                       const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
+                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords, YkFrameStrides fs) {
+    __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_off[YK_SCAN_TILE];
+    __shared__ uint8_t s_cnt[YK_SCAN_TILE];
+    {   // blockIdx.z = frame of a batch
+        const size_t f = blockIdx.z;
+        tileCount += f * fs.tileCount; tileDef += f * fs.tileDef; slots += f * fs.slots; blockSums += f * fs.blockN;
+        defsOut += f * fs.defsOut; nibOut += f * (fs.nibOut / 4);
+    }
+    const int p = blockIdx.y;
+    const size_t i0 = (size_t)blockIdx.x * YK_SCAN_TILE;
+    {
+        const size_t i = i0 + threadIdx.x;
+        const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+        uint32_t totN, totD;
+        const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
+        const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
+        const uint32_t baseN = blockSums[(size_t)blockIdx.x * 2], baseD = blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
+        s_off[threadIdx.x] = (baseN + en) >> 1;                                   // byte offset inside the plane's stream
+        s_cnt[threadIdx.x] = (uint8_t)c;
+        if (c) defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
+    }
+    __syncthreads();
+    uint8_t* out = reinterpret_cast<uint8_t*>(nibOut + (size_t)p * nibStrideWords);
+    const int piece = threadIdx.x & 3;
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 256 + (threadIdx.x >> 2);
+        const size_t i = i0 + t;
+        if (i >= T8) break;
+        if (piece * 8 < (s_cnt[t] >> 1))
+            *reinterpret_cast<uint2*>(out + s_off[t] + piece * 8) = *reinterpret_cast<const uint2*>(slots + ((size_t)p * T8 + i) * YK_SLOT + piece * 8);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+// test hook: the launcher of an independent second implementation of the fused kernel (same YkEncodeParams, same outputs)
+static int (*g_crossCheckLauncher)(hipStream_t, const YkEncodeParams*) = nullptr;
+extern "C" int yk_set_cross_check_launcher(void* fn) { g_crossCheckLauncher = reinterpret_cast<int (*)(hipStream_t, const YkEncodeParams*)>(fn); return YK_OK; }
+
+int yk_launch_alpha(yk_ctx* c, bool batch) {
+    const int F = batch ? c->nFrames : 1;
+    uint8_t* keep = batch ? c->B.keep : c->keep;
+    int32_t* bounds = batch ? c->B.bounds : c->bounds;
+    const int32_t* alpha = batch ? c->B.plane[3] : c->plane[3];
+    const size_t nFlags = ((size_t)c->mtW * c->mtH + 3) & ~(size_t)3;
+    YK_HIP(c, hipMemsetAsync(keep, 0, F > 1 ? (size_t)c->fs.keep * F : nFlags, c->stream));
+    const long long nUnits = (long long)((c->fullW / 4 + 1023) / 1024) * c->h * F;
+    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < 4096 ? nUnits : 4096)), dim3(256), 0, c->stream, alpha, c->strideElems, c->fullW, c->h,
+                       keep, c->mtW, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep);
+    YK_HIP(c, hipGetLastError());
+    const int nb = (int)((nFlags / 4 + 1023) / 1024);
+    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 128 ? nb : 128, F), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(keep), c->mtW, c->mtH,
+                       c->y0, bounds, c->fullW, c->fullH, (unsigned long long)(c->fs.keep / 4));
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
+
+int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox) {
+    // whole image: yk_alpha_bbox_kernel already published bounds[0..4]; stripes: the host-combined box replaces them
+    if (globalBBox) {
+        int32_t b[5] = { globalBBox[0], globalBBox[1], globalBBox[2], globalBBox[3], 0 };
+        b[4] = (b[0] == 0 && b[1] == 0 && b[2] == c->fullW && b[3] == c->fullH) ? 1 : 0;
+        YK_HIP(c, hipMemcpyAsync(c->bounds, b, sizeof b, hipMemcpyHostToDevice, c->stream));
+    }
+    return YK_OK;
+}
+
+int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch) {
+    YkEncodeParams P;
+    for (int i = 0; i < 4; i++) P.plane[i] = batch ? c->B.plane[i] : c->plane[i];
+    P.strideElems = c->strideElems; P.w = c->fullW; P.h = c->h; P.hAvail = c->h + c->halo; P.y0 = c->y0; P.fullH = c->fullH;
+    P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst; P.ablate = c->ablate;
+    P.keep = (c->nPlanes == 4) ? (batch ? c->B.keep : c->keep) : nullptr;
+    P.bounds = (c->nPlanes == 4) ? (batch ? c->B.bounds : c->bounds) : nullptr;
+    for (int i = 0; i < 7; i++) P.bitmap[i] = batch ? c->B.bitmap[i] : c->bitmap[i];
+    P.coverage = batch ? c->B.coverage : c->coverage; P.tileDef = batch ? c->B.tileDef : c->tileDef;
+    P.tileCount = batch ? c->B.tileCount : c->tileCount; P.slots = batch ? c->B.slots : c->slots;
+    P.blockCnt = c->kernelVersion == 2 ? (batch ? c->B.blockCnt : c->blockCnt) : nullptr;
+    for (int i = 0; i < 3; i++) P.dst[i] = c->dst[i];
+    P.tilesW = c->tilesW; P.tilesH = c->tilesH; P.mtW = c->mtW; P.mtH = c->mtH;
+    P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
+    P.nFrames = batch ? c->nFrames : 1; P.fs = c->fs;
+    P.qtab = c->qtab;
+    if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
+    // version 1 = the cross-check implementation of the test suite (tests/csrc/yk_encode_v1.hip), registered at run time
+    if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
+    if (!g_crossCheckLauncher) return yk_fail(c, YK_ERR_STATE, "kernel version 1 is not part of this library: register it with yk_set_cross_check_launcher");
+    if (g_crossCheckLauncher(c->stream, &P) != 0) return yk_fail(c, YK_ERR_HIP, "cross-check kernel launch", hipGetLastError());
+    return YK_OK;
+}
+
+int yk_launch_pack(yk_ctx* c, bool batch) {
+    const size_t T8 = (size_t)c->tilesW * c->tilesH;
+    const int nb = c->nScanBlocks, F = batch ? c->nFrames : 1;
+    uint32_t* blockCnt = batch ? c->B.blockCnt : c->blockCnt; uint32_t* blockSums = batch ? c->B.blockSums : c->blockSums;
+    uint32_t* totals = batch ? c->B.totals : c->totals; uint8_t* nibOut = batch ? c->B.nibOut : c->nibOut;
+    if (c->kernelVersion != 2) hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockCnt);
+    hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals, (unsigned long long)c->fs.blockN);
+    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3, F), dim3(1024), 0, c->stream, batch ? c->B.tileCount : c->tileCount, batch ? c->B.tileDef : c->tileDef,
+                       batch ? c->B.slots : c->slots, T8, blockSums, nb, batch ? c->B.defsOut : c->defsOut, reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, c->fs);
+    YK_HIP(c, hipGetLastError());
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// self-test hooks (run by tests/test_gpu_selftest.py): exhaustive checks of the arithmetic shortcuts used above
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void yk_selftest_div_kernel(int* mismatches) {
+    const int n = blockIdx.x, d = threadIdx.x + 1;           // n in 0..255, d in 1..256
+    const float fn = (float)n, fd = (float)d;
+    const float ref = __fdiv_rn(fn, fd);
+    const float got = yk_div_exact(fn, fd, __fdiv_rn(1.0f, fd));
+    if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1);
+}
+
+__global__ void yk_selftest_scale_kernel(int* mismatches) {
+    const int scale = blockIdx.x + 1, d8 = threadIdx.x;        // scale 1..256 (superset of 3..223), d8 32..255
+    if (d8 < 32) return;
+    const int dnum = (d8 - 32) * 127 + (scale - 1);
+    const int ref = dnum / scale;
+    const int got = __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
+    if (ref != got) atomicAdd(mismatches, 1);
+}
+
+__global__ void yk_selftest_r1div_kernel(int* mismatches) {
+    const int n = blockIdx.x * 16 + (threadIdx.x >> 4), d0 = (threadIdx.x & 15) * 16;     // n 0..4095, d 1..255
+    for (int k = 0; k < 16; k++) {
+        const int d = d0 + k;
+        if (d < 1 || d > 255) continue;
+        const int got = __float2int_rz(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+        if (got != n / d) atomicAdd(mismatches, 1);
+    }
+}
+
+extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
+    if (!c || !result) return YK_ERR_BAD_ARG;
+    YK_HIP(c, hipSetDevice(c->device));
+    int* d = nullptr;
+    YK_HIP(c, hipMalloc(&d, sizeof(int)));
+    YK_HIP(c, hipMemsetAsync(d, 0, sizeof(int), c->stream));
+    if (which == 0) hipLaunchKernelGGL(yk_selftest_div_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 1) hipLaunchKernelGGL(yk_selftest_scale_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 2) hipLaunchKernelGGL(yk_selftest_r1div_kernel, dim3(256), dim3(256), 0, c->stream, d);
+    else if (which == 3) yk_selftest_qtab_launch(c, d);
+    else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
+    YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    return YK_OK;
+}
