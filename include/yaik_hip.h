@@ -162,6 +162,24 @@ int    yk_partial_corners(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nByte
 /* mapSmoothTile->GetPlane(plane) != 0 per 4x4 cell, same layout as yk_coverage (equal to it until the first partial pass) */
 int    yk_coverage_plane(yk_ctx* c, int plane, uint16_t* hostOut, size_t capElems);
 
+/* ---- (f)4  3-D LUT tiles: EncoderContext::Load3DPattern (EncoderContext.cpp:7851), EvalCtx3D::Set3DPointCloud (:4744),
+ * StartCorrelationSearch (:7316), Correlation3DSearch (:6245) with computeValues3D (:5807).  Runs where Convert() runs it (:9117-9218):
+ * after the gradient passes, before the 1-D compressor, whose per-plane maps it shrinks (a matched tile covers all three planes of
+ * mapSmoothTile, not smoothMap: yk_coverage_plane grows, yk_coverage does not).
+ * yk_lut_load_pattern: one pattern of the bank = the contents of one 'Bank3D' .lut file (u8 count, r[], g[], b[], 6-bit values), at most 64
+ * points (more make the reference overrun its tables, :7907-7917) and 64 patterns; *index = its number.  The bank belongs to the handle
+ * and survives yk_set_image.  yk_lut_start allocates and clears the streams; yk_lut_search runs ONE tile shape (shiftX, shiftY) in
+ * {(4,3),(3,4),(3,3),(3,2),(2,3),(2,2)} - the reference calls them in that order - and appends to the streams; *matched = tiles taken.
+ * yk_lut_stream(which): 0 = corr3D_tileStreamTileType (u16: orientation | pattern << 6 | bitMode << 14, :6559), 1 = corr3D_colorStream
+ * (box lo RGB, hi RGB per tile, before EndCorrelationSearch's CompressF :7494), 2..5 = corr3D_stream3Bit..6Bit (entry numbers, before the
+ * x 3 of :7526), 6..11 = the tile maps of 16x8, 8x16, 8x8, 8x4, 4x8, 4x4 (BitmapSwizzleMapSize bytes, :7310).  Single whole images. */
+int yk_lut_clear(yk_ctx* c);
+int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int count, int* index);
+int yk_lut_pattern_tables(yk_ctx* c, int pattern, int16_t* factors, uint16_t* distanceField, uint8_t* positions);
+int yk_lut_start(yk_ctx* c);
+int yk_lut_search(yk_ctx* c, int tileShiftX, int tileShiftY, int* matched);
+int yk_lut_stream(yk_ctx* c, int which, uint8_t* hostOut, size_t cap, size_t* nBytes);
+
 /* range-quantiser results per plane (valid after yk_encode_tiles) ---------------------------------
  * tileDefs = `streamTileDef` u16 EncodeTileType(type,range,base) of tiles with >= 1 valid pixel, LeftRightOrder
  * (:4419,:4434-4438); nibbles = `streamTileIdx`, low nibble first (:1180-1184), closed to a whole byte (:4525). */

@@ -64,6 +64,22 @@ def _load() -> C.CDLL:
     for name in ("yko_dec_planes", "yko_dec_tile4x4", "yko_dec_map_rgb", "yko_dec_map_rgb_mask"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, ip]
+    # (f)4 3-D LUT search
+    lib.yko_lut_load.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.yko_lut_count.argtypes = [vp]
+    for name in ("yko_lut_factors", "yko_lut_distance_field", "yko_lut_preview"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, C.c_int]
+    lib.yko_lut_positions.restype = vp
+    lib.yko_lut_positions.argtypes = [vp, C.c_int, C.c_int]
+    lib.yko_lut_start.argtypes = [vp]
+    lib.yko_lut_search.argtypes = [vp, C.c_int, C.c_int]
+    for name in ("yko_lut_tile_types", "yko_lut_colors"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, ip]
+    for name in ("yko_lut_indices", "yko_lut_map"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, C.c_int, ip]
     return lib
 
 
@@ -131,6 +147,42 @@ class OracleEncoder:
         c = C.c_int()
         p = lib().yko_last_palette(self._e, C.byref(c))
         return _arr(p, c.value)
+
+    # ---- (f)4 3-D LUT tile search (Load3DPattern / Correlation3DSearch / computeValues3D) -------------------------------
+    def lut_load(self, pattern: np.ndarray) -> int:
+        """pattern: uint8 [count, 3], 6-bit coordinates (the contents of one Bank3D .lut file)."""
+        p = np.ascontiguousarray(pattern, dtype=np.uint8)
+        r, g, b = (np.ascontiguousarray(p[:, c]) for c in range(3))
+        k = lib().yko_lut_load(self._e, r.ctypes.data, g.ctypes.data, b.ctypes.data, len(p))
+        if k < 0:
+            raise ValueError("pattern rejected (1..64 points, at most 64 patterns)")
+        return k
+
+    def lut_tables(self, k: int):
+        """(factors int16 [4, 3, 64], distanceField int32 [64^3], positions uint8 [4, 64^3]) of pattern k; axis 0 = 6, 5, 4, 3 bits."""
+        L = lib()
+        fac = _arr(L.yko_lut_factors(self._e, k), 4 * 3 * 64, np.int16).reshape(4, 3, 64)
+        dist = _arr(L.yko_lut_distance_field(self._e, k), 64 ** 3, np.int32)
+        pos = np.stack([_arr(L.yko_lut_positions(self._e, k, s), 64 ** 3) for s in range(4)])
+        return fac, dist, pos
+
+    def lut_start(self) -> None:
+        lib().yko_lut_start(self._e)
+
+    def lut_search(self, sx: int, sy: int) -> int:
+        return lib().yko_lut_search(self._e, sx, sy)
+
+    def lut_streams(self) -> dict:
+        L, n = lib(), C.c_int()
+        out = {}
+        p = L.yko_lut_tile_types(self._e, C.byref(n)); out["tileType"] = _arr(p, n.value, np.uint16)
+        p = L.yko_lut_colors(self._e, C.byref(n)); out["color"] = _arr(p, n.value)
+        for bits in (3, 4, 5, 6):
+            p = L.yko_lut_indices(self._e, bits, C.byref(n)); out[f"idx{bits}"] = _arr(p, n.value)
+        for k in range(6):
+            p = L.yko_lut_map(self._e, k, C.byref(n)); out[f"map{k}"] = _arr(p, n.value)
+        out["preview"] = np.stack([_arr(L.yko_lut_preview(self._e, c), self.w * self.h, np.int32).reshape(self.h, self.w) for c in range(3)])
+        return out
 
     def state(self, name: str, plane: int = 0) -> np.ndarray:
         n = self.w * self.h
@@ -219,6 +271,12 @@ class OracleDecoder:
         n = C.c_int()
         p = lib().yko_dec_map_rgb_mask(self._d, C.byref(n))
         return _arr(p, n.value * (3 if all_planes else 1))
+
+
+def yko_compress_f(values: np.ndarray, rate: int) -> np.ndarray:
+    """CompressF (EncoderContext.cpp:3191) per byte: (v * rate + 127) / 255."""
+    v = np.ascontiguousarray(values, dtype=np.uint8).astype(np.int64)
+    return ((v * rate + 127) // 255).astype(np.uint8)
 
 
 def palette_remap(stream: np.ndarray, original_range: int = 250) -> np.ndarray:

@@ -109,6 +109,25 @@ const uint8_t* yko_dec_tile4x4(const yko_dec* d, int* sizePerPlane);
 const uint8_t* yko_dec_map_rgb(const yko_dec* d, int* nBytes);
 const uint8_t* yko_dec_map_rgb_mask(const yko_dec* d, int* sizePerPlane);
 
+/* ---- (f)4 3-D LUT tile search (yaik_oracle_lut.c) ------------------------------------------------------------
+ * Load3DPattern + Set3DPointCloud (EncoderContext.cpp:7851-7917, :4744-4814): count <= 64 points with 6-bit coordinates; returns the
+ * pattern index.  factors: s16 [4 (6,5,4,3 bit)][3 (x,y,z)][64]; positions(step): u8 [64^3] nearest entry at 6 - step bits. */
+int yko_lut_load(yko_enc* e, const uint8_t* r, const uint8_t* g, const uint8_t* b, int count);
+int yko_lut_count(const yko_enc* e);
+const int16_t* yko_lut_factors(const yko_enc* e, int pattern);
+const int32_t* yko_lut_distance_field(const yko_enc* e, int pattern);
+const uint8_t* yko_lut_positions(const yko_enc* e, int pattern, int step);
+/* StartCorrelationSearch (:7316) / Correlation3DSearch (:6245, with computeValues3D :5807) for one tile shape; the streams accumulate over
+ * the calls like the reference's corr3D_* buffers.  map: 0..5 = 16x8, 8x16, 8x8, 8x4, 4x8, 4x4.  indices(bits): raw entry numbers (the
+ * chunk stores them x 3, :7526). */
+void yko_lut_start(yko_enc* e);
+int yko_lut_search(yko_enc* e, int tileShiftX, int tileShiftY);
+const uint16_t* yko_lut_tile_types(const yko_enc* e, int* n);
+const uint8_t* yko_lut_colors(const yko_enc* e, int* n);
+const uint8_t* yko_lut_indices(const yko_enc* e, int bits, int* n);
+const uint8_t* yko_lut_map(const yko_enc* e, int which, int* n);
+const int32_t* yko_lut_preview(const yko_enc* e, int plane);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 /* TEST INFRASTRUCTURE ONLY.  The encoder state shared by the translation units of liboracle.so. */
 #pragma once
 #include "yaik_oracle.h"
+#include <stddef.h>
 
 struct yko_lut_state;
 void yko_lut_free(struct yko_lut_state* s);

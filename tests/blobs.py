@@ -154,6 +154,79 @@ def compare_partial(ref: dict, ours: dict) -> list:
     return bad
 
 
+LUT_PASSES = ((4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2))          # Correlation3DSearch calls of Convert(), EncoderContext.cpp:9144-9199
+LUT_KEEP = ("lut_counts", "lut_tileType", "lut_color", "lut_idx", "lut_map", "lut_mapSmoothTile", "lut_zin", "d1_pix", "d1_type", "d1_ends")
+
+
+def oracle_lut_blobs(planes: np.ndarray, patterns, tables: bool = True) -> dict:
+    """The blobs of `ref_driver <in> <out> lut3d <bank>`: seven RGB passes, the bank loaded, six 3-D LUT search passes, the streams as
+    EndCorrelationSearch hands them to ZStd (lut_zin_*: maps, tile types, CompressF'd colours, indices x 3), then the 1-D compressor."""
+    from oracle.pyoracle import yko_compress_f
+    n, h, w = planes.shape
+    out = {}
+    enc = OracleEncoder(planes)
+    if n == 4:
+        enc.mip_prefilter()
+    for sx, sy in PASSES:
+        enc.fitting_quad_smooth(sx, sy)
+    for k, p in enumerate(patterns):
+        enc.lut_load(p)
+        if tables:
+            fac, dist, pos = enc.lut_tables(k)
+            out[f"lut_factors_{k}"] = np.concatenate([fac[i, c, :nn] for i, nn in enumerate((64, 32, 16, 8)) for c in range(3)]).tobytes()
+            out[f"lut_distanceField_{k}"] = dist.tobytes()
+            out[f"lut_positions_{k}"] = pos.tobytes()
+    enc.lut_start()
+    counts = []
+    for sx, sy in LUT_PASSES:
+        enc.lut_search(sx, sy)
+        s = enc.lut_streams()
+        counts.append([s["tileType"].size, s["color"].size, s["idx3"].size, s["idx4"].size, s["idx5"].size, s["idx6"].size])
+    out["lut_counts"] = np.array(counts, dtype=np.int32).tobytes()
+    out["lut_tileType"] = s["tileType"].tobytes()
+    out["lut_color"] = s["color"].tobytes()
+    for bits in (3, 4, 5, 6):
+        out[f"lut_idx{bits}"] = s[f"idx{bits}"].tobytes()
+    for k in range(6):
+        out[f"lut_map_{k}"] = s[f"map{k}"].tobytes()
+    for p in range(3):
+        out[f"lut_mapSmoothTile_{p}"] = enc.state("mapSmoothTile", p).tobytes()
+    out["_lut_preview"] = s["preview"].tobytes()
+    # what EndCorrelationSearch compresses, in call order (:7397-7586): 6 maps, tile types, colours after CompressF(., 250), 3/4/5/6-bit x 3
+    zin = [s[f"map{k}"].tobytes() for k in range(6)]
+    if s["tileType"].size:
+        zin.append(s["tileType"].tobytes())
+    if s["color"].size:
+        zin.append(yko_compress_f(s["color"], 250).tobytes())
+    for bits in (3, 4, 5, 6):
+        if s[f"idx{bits}"].size:
+            zin.append((s[f"idx{bits}"].astype(np.uint16) * 3).astype(np.uint8).tobytes())
+    for k, z in enumerate(zin):
+        out[f"lut_zin_{k}"] = z
+    ends = []
+    for p in range(3):
+        enc.dynamic_tile_compressor(p)
+        pix, typ = enc.streams_1d()
+        ends.append((pix.size, typ.size))
+    out["d1_pix"] = pix.tobytes()
+    out["d1_type"] = typ.tobytes()
+    out["d1_ends"] = np.array([e[0] for e in ends] + [e[1] for e in ends], dtype=np.int32).tobytes()
+    return out
+
+
+def compare_lut(ref: dict, ours: dict, tables: bool = True) -> list:
+    bad = []
+    keep = LUT_KEEP + (("lut_factors", "lut_distanceField", "lut_positions") if tables else ())
+    for k, v in ref.items():
+        if not k.startswith(keep):
+            continue
+        if k not in ours:
+            bad.append(f"missing {k}")
+        elif bytes(v) != ours[k]:
+            bad.append(f"{k}: {len(v)} vs {len(ours[k])} bytes")
+    return bad
+
+
 def parse_mip_chunk(chunk: bytes):
     """'MIPM' chunk as written by MipPrefilter (EncoderContext.cpp:1367-1396): HeaderBase(8) + MipmapHeader(16) + bitmap.
     MipmapHeader.streamSize is never initialised by the reference, so only bbox / level / bitmap are comparable."""

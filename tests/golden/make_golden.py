@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle.refrun import have_ref, run_reference  # noqa: E402
-from tests.blobs import PP_KEEP  # noqa: E402
+from tests.blobs import LUT_KEEP, PP_KEEP  # noqa: E402
+from tests.lutbank import bank_bytes, bank_patterns, lut_image  # noqa: E402
 from tests.images import edge_image, lineart_image, natural_photo, synth_planes  # noqa: E402
 
 PHOTO_SRC = "/opt/conda/lib/python3.9/site-packages/skimage/data/astronaut.png"       # present in the build image; never read by tests
@@ -44,6 +45,10 @@ PARTIAL = {  # name -> planes factory; `ref_driver ... partial` (six partial-pla
     "pp_planemix144x80_rgb": lambda: edge_image(144, 80, "planemix", 3),
     "pp_planemix256_rgba": lambda: edge_image(256, 256, "planemix", 4),
     "pp_mixed128_rgba": lambda: edge_image(128, 128, "mixed", 4),
+}
+LUT3D = {  # name -> (planes, patterns); `ref_driver ... lut3d <bank>` with the synthetic bank of tests/lutbank.py: streams + maps + 1-D blobs
+    "lut_lutmix128_rgb": lambda: (lut_image(128, 128, seed=3), bank_patterns()),
+    "lut_lutmix192x144_rgb": lambda: (lut_image(192, 144, seed=7), bank_patterns()),
 }
 # blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
 DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_")
@@ -73,6 +78,12 @@ def main():
     for name, mk in PARTIAL.items():
         blobs = run_reference(mk(), partial=True)
         keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if k.startswith(PP_KEEP)}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, sum(v.size for v in keep.values()), "bytes raw")
+    for name, mk in LUT3D.items():
+        planes, pats = mk()
+        blobs = run_reference(planes, lut_bank=bank_bytes(pats))
+        keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if k.startswith(LUT_KEEP)}
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
         print(name, sum(v.size for v in keep.values()), "bytes raw")
     hashes = {}

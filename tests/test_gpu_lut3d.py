@@ -1,0 +1,125 @@
+"""GPU 3-D LUT tile search through the C-ABI: pattern tables, the six search passes, their streams and maps, the per-plane
+coverage they leave and the 1-D streams behind them -- against the CPU oracle and the reference fixtures (tests/golden/lut_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import PASSES, OracleEncoder
+from tests.blobs import LUT_PASSES
+from tests.golden.make_golden import LUT3D
+from tests.lutbank import bank_patterns, lut_image
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from yaik_amd.encoder import HipTileEncoder
+    e = HipTileEncoder(0)
+    yield e
+    e.close()
+
+
+def cells(plane8: np.ndarray) -> np.ndarray:
+    h, w = plane8.shape
+    return plane8[: h // 4 * 4: 4, : w // 4 * 4: 4] != 0
+
+
+def test_pattern_tables_match_oracle(hip, oracle_built):
+    """Load3DPattern's morton sort + Set3DPointCloud: factor tables, nearest-entry tables at 6/5/4/3 bits, distance field."""
+    pats = bank_patterns()
+    rng = np.random.default_rng(5)
+    pats.append(rng.integers(0, 64, (33, 3)).astype(np.uint8))             # unordered points, duplicates likely
+    pats.append(np.array([[7, 7, 7]], np.uint8))                           # a single point
+    ora = OracleEncoder(lut_image(64, 64))
+    hip.lut_clear()
+    for k, p in enumerate(pats):
+        assert ora.lut_load(p) == k and hip.lut_load(p) == k
+        fac, dist, pos = ora.lut_tables(k)
+        gfac, gdist, gpos = hip.lut_tables(k)
+        assert np.array_equal(gfac, fac), k
+        assert np.array_equal(gdist.astype(np.int32), dist), k
+        assert np.array_equal(gpos, pos), k
+    from yaik_amd._lib import YaikError
+    with pytest.raises(YaikError):
+        hip.lut_load(np.zeros((65, 3), np.uint8))
+    with pytest.raises(YaikError):
+        hip.lut_load(np.full((4, 3), 64, np.uint8))
+    hip.lut_clear()
+
+
+CASES = {
+    "lut128": lambda: (lut_image(128, 128, seed=11), bank_patterns()),
+    "lut200x136": lambda: (lut_image(200, 136, seed=5), bank_patterns()),
+    "lut256_3patterns": lambda: (lut_image(256, 256, bank_patterns(3), seed=2), bank_patterns(3)),
+    "lut512": lambda: (lut_image(512, 512, seed=9), bank_patterns()),
+    "lut256_rgba": lambda: (np.concatenate([lut_image(256, 256, seed=4), np.full((1, 256, 256), 255, np.int32)]), bank_patterns()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_lut_search_matches_oracle(hip, oracle_built, name):
+    planes, pats = CASES[name]()
+    n, h, w = planes.shape
+    ora = OracleEncoder(planes)
+    if n == 4:
+        ora.mip_prefilter()
+    for sx, sy in PASSES:
+        ora.fitting_quad_smooth(sx, sy)
+    hip.lut_clear()
+    for p in pats:
+        ora.lut_load(p); hip.lut_load(p)
+    hip.set_image(planes)
+    if n == 4:
+        hip.mip_prefilter()
+    hip.encode(3, False, False)
+    ora.lut_start(); hip.lut_start()
+    total = 0
+    for sx, sy in LUT_PASSES:
+        want = ora.lut_search(sx, sy)
+        got = hip.lut_search(sx, sy)
+        assert got == want, (sx, sy, got, want)
+        total += want
+    assert total > 0
+    so, sg = ora.lut_streams(), hip.lut_streams()
+    for k in ("tileType", "color", "idx3", "idx4", "idx5", "idx6") + tuple(f"map{i}" for i in range(6)):
+        assert np.array_equal(sg[k], so[k]), k
+    for p in range(3):
+        assert np.array_equal(hip.coverage_plane(p), cells(ora.state("mapSmoothTile", p))), p
+    assert np.array_equal(hip.coverage(), cells(ora.state("smoothMap")))          # LUT tiles never touch smoothMap
+    for p in range(3):
+        ora.dynamic_tile_compressor(p)
+    pix, typ = ora.streams_1d()
+    gpix, gtyp = hip.dynamic_tile_compressor()
+    assert np.array_equal(gtyp, typ) and np.array_equal(gpix, pix)
+    hip.lut_clear()
+
+
+@pytest.mark.parametrize("name", sorted(LUT3D))
+def test_lut_search_matches_reference_fixture(hip, name):
+    ref = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    planes, pats = LUT3D[name]()
+    hip.lut_clear()
+    for p in pats:
+        hip.lut_load(p)
+    hip.set_image(planes)
+    hip.encode(3, False, False)
+    hip.lut_start()
+    counts = np.frombuffer(ref["lut_counts"].tobytes(), np.int32).reshape(6, 6)
+    for i, (sx, sy) in enumerate(LUT_PASSES):
+        hip.lut_search(sx, sy)
+        s = hip.lut_streams()
+        assert [s["tileType"].size, s["color"].size, s["idx3"].size, s["idx4"].size, s["idx5"].size, s["idx6"].size] == counts[i].tolist(), i
+    assert np.array_equal(s["tileType"].view(np.uint8), ref["lut_tileType"]) and np.array_equal(s["color"], ref["lut_color"])
+    for bits in (3, 4, 5, 6):
+        assert np.array_equal(s[f"idx{bits}"], ref[f"lut_idx{bits}"]), bits
+    for k in range(6):
+        assert np.array_equal(s[f"map{k}"], ref[f"lut_map_{k}"]), k
+    n, h, w = planes.shape
+    for p in range(3):
+        assert np.array_equal(hip.coverage_plane(p), cells(ref[f"lut_mapSmoothTile_{p}"].reshape(h, w)))
+    gpix, gtyp = hip.dynamic_tile_compressor()
+    assert np.array_equal(gpix, ref["d1_pix"]) and np.array_equal(gtyp, ref["d1_type"])
+    hip.lut_clear()

@@ -64,6 +64,12 @@ SIGNATURES = {
     "yk_partial_bitmap": (C.c_int, [vp, vp, sz, szp]),
     "yk_partial_corners": (C.c_int, [vp, vp, sz, szp]),
     "yk_coverage_plane": (C.c_int, [vp, C.c_int, vp, sz]),
+    "yk_lut_clear": (C.c_int, [vp]),
+    "yk_lut_load_pattern": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "yk_lut_pattern_tables": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "yk_lut_start": (C.c_int, [vp]),
+    "yk_lut_search": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "yk_lut_stream": (C.c_int, [vp, C.c_int, vp, sz, szp]),
     "yk_gradient_corner_edges": (C.c_int, [vp, vp, vp, sz]),
     "yk_range_sizes": (C.c_int, [vp, C.c_int, szp, szp]),
     "yk_range_streams": (C.c_int, [vp, C.c_int, vp, sz, vp, sz]),

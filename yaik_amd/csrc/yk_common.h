@@ -103,6 +103,8 @@ struct yk_ctx {
     uint8_t* mapped3 = nullptr;                            // bit p = plane p's corner at this lattice point has been emitted
     uint32_t* ppBitmap = nullptr; size_t ppBitmapBytes = 0; uint8_t* ppStream = nullptr; size_t ppStreamCap = 0, ppStreamBytes = 0;
     uint32_t* ppScratch = nullptr; size_t ppScratchElems = 0, ppBitmapCap = 0; int ppAccepted = 0; bool ppActive = false;
+    // (f)4 3-D LUT tiles (yk_lut3d.hip): pattern bank + the streams StartCorrelationSearch allocates
+    struct YkLutState* lut = nullptr;
     // live 1-D range path (a15)
     uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
     uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;
@@ -144,6 +146,8 @@ int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
 int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch = false);
 int yk_launch_pack(yk_ctx* c, bool batch = false);
 int yk_launch_corners(yk_ctx* c);
+void yk_lut_destroy(yk_ctx* c);                          // frees the 3-D LUT bank and streams (yk_lut3d.hip)
+int yk_pp_activate(yk_ctx* c);                           // per-plane coverage / corner flags for the passes behind the RGB passes
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P);
 int yk_qtab_get(yk_ctx* c);                              // builds the device's quantiser table on first use, sets c->qtab
 void yk_selftest_qtab_launch(yk_ctx* c, int* mismatches);

@@ -145,6 +145,28 @@ __global__ __launch_bounds__(256) void yk_pp_mark_kernel(const uint32_t* __restr
     if (i < lat && owner[i] != 0xFFFFFFFFu) mapped3[i] |= (uint8_t)planeBit;
 }
 
+// Per-plane state of the passes that follow the seven RGB passes (plane-subset gradient passes, 3-D LUT tiles): every plane starts from
+// the common coverage, every lattice point an RGB pass emitted is known to all planes.  Idempotent until the next encode.
+int yk_pp_activate(yk_ctx* c) {
+    if (c->ppActive) return YK_OK;
+    const int w = c->fullW, h = c->h, latW = w / 4 + 1, latH = h / 4 + 1;
+    const size_t lat = (size_t)latW * latH, nMT = (size_t)c->mtW * c->mtH;
+    // the corner lattice of the RGB passes must exist: it tells which lattice points every plane already has
+    if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
+    c->covChStride = (nMT + 7) & ~(size_t)7;
+    if (!c->covCh) {
+        YK_HIP(c, hipMalloc(&c->covCh, 3 * c->covChStride * sizeof(uint16_t) + 16));
+        YK_HIP(c, hipMalloc(&c->mapped3, lat + 16));
+    }
+    YK_HIP(c, hipMemsetAsync(c->covCh, 0, 3 * c->covChStride * sizeof(uint16_t) + 16, c->stream));
+    const size_t n = nMT > lat ? nMT : lat;
+    hipLaunchKernelGGL(yk_pp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->coverage, nMT, c->covCh, c->covChStride,
+                       c->latticeOwner, lat, c->mapped3);
+    YK_HIP(c, hipGetLastError());
+    c->ppActive = true;
+    return YK_OK;
+}
+
 extern "C" {
 
 int yk_gradient_partial_pass(yk_ctx* c, int rejectFactor, int planeBit, int sx, int sy, int* tilesAccepted) {
@@ -159,21 +181,7 @@ int yk_gradient_partial_pass(yk_ctx* c, int rejectFactor, int planeBit, int sx, 
     YK_HIP(c, hipSetDevice(c->device));
     const int w = c->fullW, h = c->h, latW = w / 4 + 1, latH = h / 4 + 1;
     const size_t lat = (size_t)latW * latH, nMT = (size_t)c->mtW * c->mtH;
-    if (!c->ppActive) {
-        // the corner lattice of the RGB passes must exist: it tells which lattice points every plane already has
-        if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
-        c->covChStride = (nMT + 7) & ~(size_t)7;
-        if (!c->covCh) {
-            YK_HIP(c, hipMalloc(&c->covCh, 3 * c->covChStride * sizeof(uint16_t) + 16));
-            YK_HIP(c, hipMalloc(&c->mapped3, lat + 16));
-        }
-        YK_HIP(c, hipMemsetAsync(c->covCh, 0, 3 * c->covChStride * sizeof(uint16_t) + 16, c->stream));
-        const size_t n = nMT > lat ? nMT : lat;
-        hipLaunchKernelGGL(yk_pp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->coverage, nMT, c->covCh, c->covChStride,
-                           c->latticeOwner, lat, c->mapped3);
-        YK_HIP(c, hipGetLastError());
-        c->ppActive = true;
-    }
+    { int rc = yk_pp_activate(c); if (rc) return rc; }
     const PPGeo g = yk_pp_geo(sx, sy, w);
     const size_t nBits = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount, nWords = (nBits + 31) / 32, nb = (nBits + 1023) / 1024;
     const size_t needScratch = lat + nb + 64;

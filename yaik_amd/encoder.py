@@ -201,6 +201,44 @@ class HipTileEncoder:
         cells = bits.reshape(mth, mtw, 4, 4).transpose(0, 2, 1, 3).reshape(mth * 4, mtw * 4)
         return cells[: self.h // 4, : self.w // 4].astype(bool)
 
+    # ---- (f)4 3-D LUT tiles (Load3DPattern / StartCorrelationSearch / Correlation3DSearch) ----------------------------
+    def lut_clear(self) -> None:
+        _chk(self._h, lib().yk_lut_clear(self._h))
+
+    def lut_load(self, pattern: np.ndarray) -> int:
+        """pattern: uint8 [count, 3] with 6-bit coordinates (one Bank3D .lut file).  Returns the pattern's number."""
+        p = np.ascontiguousarray(pattern, dtype=np.uint8)
+        r, g, b = (np.ascontiguousarray(p[:, k]) for k in range(3))
+        idx = C.c_int()
+        _chk(self._h, lib().yk_lut_load_pattern(self._h, r.ctypes.data, g.ctypes.data, b.ctypes.data, len(p), C.byref(idx)))
+        return int(idx.value)
+
+    def lut_tables(self, k: int):
+        fac = np.zeros((4, 3, 64), np.int16); dist = np.zeros(64 ** 3, np.uint16); pos = np.zeros((4, 64 ** 3), np.uint8)
+        _chk(self._h, lib().yk_lut_pattern_tables(self._h, k, fac.ctypes.data, dist.ctypes.data, pos.ctypes.data))
+        return fac, dist, pos
+
+    def lut_start(self) -> None:
+        _chk(self._h, lib().yk_lut_start(self._h))
+
+    def lut_search(self, sx: int, sy: int) -> int:
+        n = C.c_int()
+        _chk(self._h, lib().yk_lut_search(self._h, sx, sy, C.byref(n)))
+        return int(n.value)
+
+    def lut_streams(self) -> dict:
+        L = lib()
+        out = {}
+        names = ["tileType", "color", "idx3", "idx4", "idx5", "idx6"] + [f"map{k}" for k in range(6)]
+        for which, name in enumerate(names):
+            nb = C.c_size_t()
+            _chk(self._h, L.yk_lut_stream(self._h, which, None, 0, C.byref(nb)))
+            buf = np.zeros(nb.value, np.uint8)
+            if buf.size:
+                _chk(self._h, L.yk_lut_stream(self._h, which, buf.ctypes.data, buf.size, None))
+            out[name] = buf.view(np.uint16) if name == "tileType" else buf
+        return out
+
     def gradient_corner_edges(self):
         """(keys[2, w/4+1], index[2, w/4+1]) of the stripe's first and last lattice rows (see yk_gradient_corner_edges)."""
         n = self.w // 4 + 1
