@@ -234,6 +234,17 @@ int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, cons
 /* UpdateTileAndRGBMask alone (decoder/YAIK_API.cpp:530-544): what a plane-subset chunk of any OTHER tile shape still does before its
  * decoder returns without work (YAIK_Gradient.cpp:29-36).  Idempotent. */
 int yk_decode_split_masks(yk_ctx* c);
+/* ---- (f)4 decode: YAIK_AssignLUT (decoder/YAIK_API.cpp:133-415) and the '3DTL' chunk, Tile3D_16x8 .. Tile3D_4x4 (decoder/YAIK_3DTile.cpp:244-2140,
+ * chunk reader YAIK_API.cpp:1002-1270).  yk_decode_assign_lut takes the decoder's LUT file ('LUL0': LUTHeader + per depth 3..6 and pattern the
+ * x, y, z entry lists) and lays out the 48 orientation tables per pattern and depth in HBM; it belongs to the handle until replaced.
+ * yk_decode_lut3d runs the six tile shapes in chunk order on host streams: maps[k] / mapBytes[k] (16x8, 8x16, 8x8, 8x4, 4x8, 4x4; NULL or 0 =
+ * absent), tiles (u16 per tile), colors (6 bytes per tile AFTER PaletteFullRangeRemapping), idx[f] / idxBytes[f] = the 3 / 4 / 5 / 6 bit index
+ * streams as stored (entry number x 3).  Pixels of 4x4 cells tile4x4Mask already marks are skipped (and consume no index), every cell of a
+ * decoded tile is marked afterwards.  consumed[6] = bytes used of tiles, colors and the four index streams.  Must come before '1DTL' /
+ * plane-subset chunks (single-plane masks), like in the file. */
+int yk_decode_assign_lut(yk_ctx* c, const uint8_t* lutFile, size_t lutBytes);
+int yk_decode_lut3d(yk_ctx* c, const uint8_t* const maps[6], const size_t mapBytes[6], const uint16_t* tiles, size_t nTiles, const uint8_t* colors,
+                    const uint8_t* const idx[4], const size_t idxBytes[4], size_t consumed[6]);
 /* Decompress1D x3 planes (decoder/YAIK_3DTile.cpp:24-240) on the '1DTL' streams (type: 3 B/tile, pix: 1 B/pixel) */
 int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes,
                  int compressionRange);

@@ -80,6 +80,8 @@ def _load() -> C.CDLL:
     for name in ("yko_lut_indices", "yko_lut_map"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, C.c_int, ip]
+    lib.yko_lut_file.argtypes = [vp, vp, C.c_int]
+    lib.yko_dec_lut3d.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
     return lib
 
 
@@ -166,6 +168,13 @@ class OracleEncoder:
         pos = np.stack([_arr(L.yko_lut_positions(self._e, k, s), 64 ** 3) for s in range(4)])
         return fac, dist, pos
 
+    def lut_file(self) -> np.ndarray:
+        """The decoder's 'LUL0' LUT file for the loaded bank (what RegisterAndCreate3DLut writes to LutFile.lut)."""
+        n = lib().yko_lut_file(self._e, None, 0)
+        out = np.zeros(n, np.uint8)
+        lib().yko_lut_file(self._e, out.ctypes.data, n)
+        return out
+
     def lut_start(self) -> None:
         lib().yko_lut_start(self._e)
 
@@ -240,6 +249,22 @@ class OracleDecoder:
         rgb_dq = np.ascontiguousarray(rgb_dq, dtype=np.uint8)
         return lib().yko_dec_gradient_planes(self._d, plane_bit, int(consistent_marks), bitmap.ctypes.data, bitmap.size,
                                              rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size)
+
+    def lut3d(self, lut_file: np.ndarray, maps, tiles: np.ndarray, colors_dq: np.ndarray, idx) -> np.ndarray:
+        """Tile3D_16x8 .. 4x4 on the streams of a '3DTL' chunk (maps: the six tile maps in chunk order; colors_dq: after
+        PaletteFullRangeRemapping; idx: the 3/4/5/6-bit index streams as stored, x 3).  Returns the bytes consumed per stream."""
+        pad = lambda a, n, dt=np.uint8: np.ascontiguousarray(np.concatenate([np.asarray(a, dt).ravel(), np.zeros(n, dt)]))
+        lf = np.ascontiguousarray(lut_file, np.uint8)
+        mp = [pad(m, 64) for m in maps]
+        ix = [pad(i, 256) for i in idx]
+        t = pad(tiles, 32, np.uint16); cdq = pad(colors_dq, 64)
+        mptr = (C.c_void_p * 6)(*[m.ctypes.data for m in mp])
+        iptr = (C.c_void_p * 4)(*[i.ctypes.data for i in ix])
+        used = np.zeros(6, np.int32)
+        rc = lib().yko_dec_lut3d(self._d, lf.ctypes.data, lf.size, mptr, t.ctypes.data, int(np.asarray(tiles).size), cdq.ctypes.data, iptr, used.ctypes.data)
+        if rc:
+            raise ValueError("invalid LUT file")
+        return used
 
     def split_masks(self):
         lib().yko_dec_split_masks(self._d)

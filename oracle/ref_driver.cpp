@@ -233,6 +233,7 @@ int main(int argc, char** argv) {
 
     // ---- (f)4 3D-LUT tiles: Load3DPattern (:7851), Set3DPointCloud (:4744), Correlation3DSearch (:6245) with computeValues3D (:5807),
     // EndCorrelationSearch (:7366).  Runs where Convert() runs it: after the gradient passes, before the 1-D compressor.
+    std::vector<Capture> lutZin; std::vector<u8> lutHeader, lutFile;
     if (lut3d) {
         int nPat = 0;
         for (size_t off = 0; off < bankBytes.size(); nPat++) {
@@ -293,6 +294,18 @@ int main(int argc, char** argv) {
         fseek(ctx->outFile, after, SEEK_SET);
         blob("lut_chunk_header", chunk.data(), chunk.size() < 8 + sizeof(HeaderTile3D) ? chunk.size() : 8 + sizeof(HeaderTile3D));
         for (size_t k = 0; k < gZstd.size(); k++) blob(nm("lut_zin", (int)k), gZstd[k].data.data(), gZstd[k].data.size());
+        lutZin.assign(gZstd.begin(), gZstd.end());
+        lutHeader.resize(sizeof(HeaderTile3D));
+        if (chunk.size() >= 8 + sizeof(HeaderTile3D)) memcpy(lutHeader.data(), chunk.data() + 8, sizeof(HeaderTile3D));
+        // the decoder's LUT file 'LUL0' as RegisterAndCreate3DLut writes it (:7820-7847; that function itself only loads the reference's
+        // hard-coded bank file names and returns at once when patterns are already loaded): header + BinarySave3D (:5452) per depth and pattern
+        LUTHeader hd; memset(&hd, 0, sizeof hd);
+        hd.lutH[0] = 'L'; hd.lutH[1] = 'U'; hd.lutH[2] = 'L'; hd.lutH[3] = '0'; hd.version = 0; hd.entryCount = (u8)(nPat - 1); hd.padding_extension[0] = 1;
+        lutFile.resize(sizeof hd + (size_t)(64 + 32 + 16 + 8) * 3 * nPat);
+        memcpy(lutFile.data(), &hd, sizeof hd);
+        u8* fill = lutFile.data() + sizeof hd;
+        for (int n = 0; n < 4; n++) for (int m = 0; m < nPat; m++) fill = ctx->correlationPattern3D[m].BinarySave3D(fill, 0, (EncoderContext::Mode)n);
+        blob("lut_file", lutFile.data(), lutFile.size());
     }
 
     // ---- a6 with nullable planes: the partial-plane 4x4 passes (PlaneBit :3715, per-plane allow :3871-3875, per-plane paint :4031-4034)
@@ -392,6 +405,61 @@ int main(int argc, char** argv) {
     }
     blob("dec_planes_grad", planes.data(), planes.size());
     blob("dec_tile4x4", t4.data(), inst.tile4x4MaskSize);
+    if (lut3d && !lutFile.empty() && lutHeader.size() == sizeof(HeaderTile3D)) {
+        // ---- (f)4 decode: Tile3D_16x8 .. Tile3D_4x4 (decoder/YAIK_3DTile.cpp:244-2140) in the order of the '3DTL' chunk reader
+        // (decoder/YAIK_API.cpp:1002-1270), on the streams EndCorrelationSearch compressed.  The per-orientation tables are laid out by
+        // YAIK_AssignLUT (YAIK_API.cpp:133-415), which is in the translation unit that cannot be built here: the layout below is harness
+        // plumbing that follows its comment block and loops (per depth: [pattern][64 slots, 48 used: 6 axis orders x 8 flips][entry][3]).
+        HeaderTile3D h3; memcpy(&h3, lutHeader.data(), sizeof h3);
+        const int nPat = lutFile[5] + 1;
+        std::vector<std::vector<u8>> tbl(4);
+        const u8* stream = lutFile.data() + sizeof(LUTHeader);
+        for (int bit = 3; bit <= 6; bit++) {
+            const int len = 1 << bit;
+            std::vector<u8>& T = tbl[bit - 3];
+            T.assign((size_t)len * 3 * 64 * 256 + 256 * 3, 251);
+            u8* pFill = T.data();
+            for (int e = 0; e < nPat; e++) {
+                const u8* o[3] = { stream, stream + len, stream + 2 * len };
+                static const int axis[6][3] = { {0,1,2}, {0,2,1}, {1,0,2}, {1,2,0}, {2,0,1}, {2,1,0} };
+                for (int pat = 0; pat < 6; pat++)
+                    for (int flip = 0; flip < 8; flip++)
+                        for (int idx = 0; idx < len; idx++)
+                            for (int c = 0; c < 3; c++) { const u8 v = o[axis[pat][c]][idx]; *pFill++ = ((flip >> c) & 1) ? (u8)(128 - v) : v; }
+                memset(pFill, 251, (size_t)16 * 3 * len); pFill += (size_t)16 * 3 * len;
+                stream += len * 3;
+            }
+        }
+        u8* TBL[4] = { tbl[0].data(), tbl[1].data(), tbl[2].data(), tbl[3].data() };
+        // the captured ZStd inputs, in EndCorrelationSearch's call order: 6 maps, [tile types], [colours], [3], [4], [5], [6] bit
+        size_t zi = 6;
+        std::vector<u8> maps[6];
+        for (int k = 0; k < 6; k++) { maps[k] = lutZin[k].data; maps[k].resize(maps[k].size() + 64, 0); }
+        std::vector<u8> tiles, colors, idxs[4];
+        if (h3.streamTypeCnt) tiles = lutZin[zi++].data;
+        if (h3.streamColorCnt) colors = lutZin[zi++].data;
+        const u32 cnts[4] = { h3.stream3BitCnt, h3.stream4BitCnt, h3.stream5BitCnt, h3.stream6BitCnt };
+        for (int k = 0; k < 4; k++) if (cnts[k]) idxs[k] = lutZin[zi++].data;
+        tiles.resize(tiles.size() + 64, 0); colors.resize(colors.size() + 64, 0);
+        for (int k = 0; k < 4; k++) idxs[k].resize(idxs[k].size() + 256, 0);
+        PaletteFullRangeRemapping(colors.data(), h3.compressionRateColor, (int)h3.streamColorCnt);      // YAIK_API.cpp:1102
+        TileParam tpm; memset(&tpm, 0, sizeof tpm);
+        tpm.stream3Bit = idxs[0].data(); tpm.stream4Bit = idxs[1].data(); tpm.stream5Bit = idxs[2].data(); tpm.stream6Bit = idxs[3].data();
+        tpm.tileStream = (u16*)tiles.data(); tpm.colorStream = colors.data();
+        typedef void (*T3)(YAIK_Instance*, HeaderTile3D*, TileParam*, u8**);
+        T3 t3[6] = { Tile3D_16x8, Tile3D_8x16, Tile3D_8x8, Tile3D_8x4, Tile3D_4x8, Tile3D_4x4 };
+        for (int k = 0; k < 6; k++) {
+            bool any = false; for (size_t i = 0; i + 64 < maps[k].size() + 0 && !any; i++) any = maps[k][i] != 0;
+            if (!any) continue;                                           // CheckTileCount == 0 -> not called (YAIK_API.cpp:1111)
+            tpm.currentMap = maps[k].data();
+            t3[k](&inst, &h3, &tpm, TBL);
+        }
+        int used[6] = { (int)((u8*)tpm.tileStream - tiles.data()), (int)(tpm.colorStream - colors.data()), (int)(tpm.stream3Bit - idxs[0].data()),
+                        (int)(tpm.stream4Bit - idxs[1].data()), (int)(tpm.stream5Bit - idxs[2].data()), (int)(tpm.stream6Bit - idxs[3].data()) };
+        blob("lut_dec_consumed", used, sizeof used);
+        blob("lut_dec_planes", planes.data(), planes.size());
+        blob("lut_dec_tile4x4", t4.data(), inst.tile4x4MaskSize);
+    }
     blob("dec_mapRGB", mapRGB.data(), mapRGB.size());
     blob("dec_mapRGBMask", mapMask.data(), sizeMask);
 

@@ -619,16 +619,6 @@ int yko_palette_decompress(const uint8_t* input, int inputSize, uint8_t* output,
 
 /* ------------------------------------------------------------------------------------------- */
 /* decoder side: YAIK_Instance buffers as allocated by YAIK_DecodeImage (decoder/YAIK_API.cpp:650-657, 855-874) */
-struct yko_dec {
-    int w, h, tileW, tileH, planeSize;
-    uint8_t* planes;        /* R|G|B, 8x8-tiled u8 (include/YAIK.h:205-224) */
-    int strideRGBMap, lattice;
-    uint8_t* mapRGB;        /* lattice*3 */
-    uint8_t* mapRGBMask; int sizeMapMask;
-    uint8_t* tile4x4Mask; int tile4x4MaskSize, stride4;
-    int singleRGB;          /* masks still in single-plane form (YAIK_Instance::singleRGB) */
-};
-
 yko_dec* yko_dec_create(int w, int h) {
     yko_dec* d = (yko_dec*)calloc(1, sizeof *d);
     d->w = w; d->h = h; d->tileW = (w + 7) >> 3; d->tileH = (h + 7) >> 3;

@@ -127,6 +127,13 @@ const uint8_t* yko_lut_colors(const yko_enc* e, int* n);
 const uint8_t* yko_lut_indices(const yko_enc* e, int bits, int* n);
 const uint8_t* yko_lut_map(const yko_enc* e, int which, int* n);
 const int32_t* yko_lut_preview(const yko_enc* e, int plane);
+/* the decoder's 'LUL0' LUT file for the loaded bank (RegisterAndCreate3DLut :7820-7847 / BinarySave3D :5452); out == NULL: size */
+int yko_lut_file(const yko_enc* e, uint8_t* out, int cap);
+/* YAIK_AssignLUT's tables (decoder/YAIK_API.cpp:133-415) + Tile3D_16x8 .. 4x4 (decoder/YAIK_3DTile.cpp:244-2140) on the streams of a '3DTL'
+ * chunk: maps in chunk order (16x8, 8x16, 8x8, 8x4, 4x8, 4x4), colours after PaletteFullRangeRemapping, indices as stored (x 3).
+ * consumed: bytes of tile types, colours, 3/4/5/6-bit indices.  Runs before the masks are split (the chunk precedes '1DTL'). */
+int yko_dec_lut3d(yko_dec* d, const uint8_t* lutFile, int lutBytes, const uint8_t* const maps[6], const uint16_t* tiles, int nTiles,
+                  const uint8_t* colors, const uint8_t* const idx[4], int consumed[6]);
 
 #ifdef __cplusplus
 }

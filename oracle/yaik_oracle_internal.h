@@ -31,3 +31,14 @@ struct yko_enc {
     struct yko_lut_state* lut;      /* (f)4 3-D LUT search state (yaik_oracle_lut.c), NULL until the first pattern is loaded */
 };
 
+
+struct yko_dec {
+    int w, h, tileW, tileH, planeSize;
+    uint8_t* planes;        /* R|G|B, 8x8-tiled u8 (include/YAIK.h:205-224) */
+    int strideRGBMap, lattice;
+    uint8_t* mapRGB;        /* lattice*3 */
+    uint8_t* mapRGBMask; int sizeMapMask;
+    uint8_t* tile4x4Mask; int tile4x4MaskSize, stride4;
+    int singleRGB;          /* masks still in single-plane form (YAIK_Instance::singleRGB) */
+};
+

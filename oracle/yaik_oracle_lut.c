@@ -309,3 +309,74 @@ const uint8_t* yko_lut_colors(const yko_enc* e, int* n) { *n = e->lut->nColor; r
 const uint8_t* yko_lut_indices(const yko_enc* e, int bits, int* n) { *n = e->lut->nIdx[bits - 3]; return e->lut->idx[bits - 3]; }
 const uint8_t* yko_lut_map(const yko_enc* e, int which, int* n) { *n = e->lut->mapBytes[which]; return e->lut->map[which]; }
 const int32_t* yko_lut_preview(const yko_enc* e, int plane) { return e->lut->preview[plane]; }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Decoder side.  YAIK_AssignLUT (decoder/YAIK_API.cpp:133-415): the 'LUL0' file (LUTHeader, then per depth 3..6 and pattern the x, y, z
+ * entry lists BinarySave3D wrote, EncoderContext.cpp:5452) becomes, per depth, [pattern][64 slots, 48 used = 6 axis orders x 8 flips]
+ * [entry][3].  Tile3D_16x8 .. Tile3D_4x4 (decoder/YAIK_3DTile.cpp:244-2140): for every set bit of a pass's tile map, in scan order, pop
+ * 6 colour bytes and a tile word (orientation | pattern << 6, depth in bits 14-15), then one pre-multiplied index per pixel of every 4x4
+ * cell of the tile that tile4x4Mask does not mark yet -- 8x8 block by block (left before right, top before bottom), rows of a block
+ * top down -- colour = lo + ((hi - lo) * entry >> 7); afterwards every cell of the tile is marked. */
+int yko_lut_file(const yko_enc* e, uint8_t* out, int cap) {                  /* what RegisterAndCreate3DLut writes to LutFile.lut (:7820-7847) */
+    const struct yko_lut_state* S = e->lut;
+    const int n = 8 + (64 + 32 + 16 + 8) * 3 * S->nPat;
+    if (!out) return n;
+    if (cap < n) return -1;
+    memset(out, 0, 8);
+    out[0] = 'L'; out[1] = 'U'; out[2] = 'L'; out[3] = '0'; out[4] = 0; out[5] = (uint8_t)(S->nPat - 1); out[6] = 1;     /* padding_extension[0] = 0 then = 1 (:7824-7825) */
+    uint8_t* w = out + 8;
+    for (int depth = 3; depth >= 0; depth--)                                  /* file order: 3, 4, 5, 6 bit; fac[] order: 6, 5, 4, 3 */
+        for (int k = 0; k < S->nPat; k++)
+            for (int c = 0; c < 3; c++) for (int m = 0; m < (64 >> depth); m++) *w++ = (uint8_t)S->pat[k].fac[depth][c][m];
+    return n;
+}
+
+int yko_dec_lut3d(yko_dec* d, const uint8_t* lutFile, int lutBytes, const uint8_t* const maps[6], const uint16_t* tiles, int nTiles,
+                  const uint8_t* colors /* after PaletteFullRangeRemapping */, const uint8_t* const idx[4] /* 3,4,5,6 bit, x 3 */, int consumed[6]) {
+    if (lutBytes < 8 || lutFile[0] != 'L' || lutFile[1] != 'U' || lutFile[2] != 'L') return -1;
+    const int nPat = lutFile[5] + 1;
+    if (lutBytes != 8 + nPat * 3 * (64 + 32 + 16 + 8)) return -1;
+    const uint8_t* depthBase[4]; { const uint8_t* p = lutFile + 8; for (int b = 0; b < 4; b++) { depthBase[b] = p; p += (size_t)(8 << b) * 3 * nPat; } }
+    static const int axis[6][3] = { {0,1,2}, {0,2,1}, {1,0,2}, {1,2,0}, {2,0,1}, {2,1,0} };
+    static const int sz[6][2] = { {4,3}, {3,4}, {3,3}, {3,2}, {2,3}, {2,2} };
+    int used[6] = { 0, 0, 0, 0, 0, 0 };                                       /* tiles, colour bytes, 3/4/5/6-bit indices */
+    for (int k = 0; k < 6; k++) {
+        const int sx = sz[k][0], sy = sz[k][1], TX = 1 << sx, TY = 1 << sy;
+        int bigX, bigY, bitCount; swizzle_size_lut(sx, sy, &bigX, &bigY, &bitCount);
+        const int xBB = (d->w + bigX - 1) / bigX, yBB = (d->h + bigY - 1) / bigY, tpr = bigX / TX;
+        for (int by = 0; by < yBB; by++) for (int bx = 0; bx < xBB; bx++) for (int t = 0; t < bitCount; t++) {
+            const int pos = (by * xBB + bx) * bitCount + t;
+            if (!((maps[k][pos >> 3] >> (pos & 7)) & 1)) continue;
+            const int x0 = bx * bigX + (t % tpr) * TX, y0 = by * bigY + (t / tpr) * TY;
+            if (x0 >= d->w || y0 >= d->h || used[0] >= nTiles) continue;
+            const uint8_t* RGB = colors + used[1]; used[1] += 6;
+            const int tile = tiles[used[0]++], fmt = (tile >> 14) & 3, len = 8 << fmt;
+            const int pattern = (tile >> 6) & 255, orient = tile & 63;
+            const uint8_t* src = idx[fmt] + used[2 + fmt];
+            int n = 0;
+            const int diff[3] = { RGB[3] - RGB[0], RGB[4] - RGB[1], RGB[5] - RGB[2] };
+            const int xCount = TX > 8 ? 2 : 1, lX = TX > 8 ? 8 : TX;
+            for (int xa = 0; xa < xCount; xa++) for (int y = 0; y < TY; y++) for (int x = 0; x < lX; x++) {
+                const int gx = x0 + x + xa * 8, gy = y0 + y, cx = gx >> 2, cy = gy >> 2;
+                const int byteI = (cx >> 2) + (cy >> 1) * d->stride4, bit = (((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1);
+                if ((d->tile4x4Mask[byteI] >> bit) & 1) continue;
+                const int e3 = src[n++];                                       /* entry number x 3 */
+                const int entry = e3 / 3;
+                for (int c = 0; c < 3; c++) {
+                    int v = 251;                                                /* slots 48..63 and patterns beyond the file hold filler (:400-404) */
+                    if (pattern < nPat && orient < 48 && entry < len) {
+                        v = depthBase[fmt][(size_t)pattern * len * 3 + (size_t)axis[orient >> 3][c] * len + entry];
+                        if ((orient >> c) & 1) v = 128 - v;
+                    }
+                    d->planes[(size_t)c * d->planeSize + ((size_t)(gy >> 3) * d->tileW + (gx >> 3)) * 64 + (gy & 7) * 8 + (gx & 7)] = (uint8_t)(RGB[c] + ((diff[c] * v) >> 7));
+                }
+            }
+            used[2 + fmt] += n;
+            for (int cy = y0 >> 2; cy < (y0 + TY) >> 2; cy++) for (int cx = x0 >> 2; cx < (x0 + TX) >> 2; cx++)
+                d->tile4x4Mask[(cx >> 2) + (cy >> 1) * d->stride4] |= (uint8_t)(1 << ((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1)));
+        }
+    }
+    used[0] *= 2;                                                              /* bytes of the tile stream, like the other counters */
+    if (consumed) memcpy(consumed, used, sizeof used);
+    return 0;
+}

@@ -155,20 +155,23 @@ def compare_partial(ref: dict, ours: dict) -> list:
 
 
 LUT_PASSES = ((4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2))          # Correlation3DSearch calls of Convert(), EncoderContext.cpp:9144-9199
-LUT_KEEP = ("lut_counts", "lut_tileType", "lut_color", "lut_idx", "lut_map", "lut_mapSmoothTile", "lut_zin", "d1_pix", "d1_type", "d1_ends")
+LUT_KEEP = ("lut_counts", "lut_tileType", "lut_color", "lut_idx", "lut_map", "lut_mapSmoothTile", "lut_zin", "lut_file", "lut_dec_", "d1_pix", "d1_type",
+            "d1_ends", "dec_1d_consumed", "dec_planes_full")
 
 
 def oracle_lut_blobs(planes: np.ndarray, patterns, tables: bool = True) -> dict:
     """The blobs of `ref_driver <in> <out> lut3d <bank>`: seven RGB passes, the bank loaded, six 3-D LUT search passes, the streams as
     EndCorrelationSearch hands them to ZStd (lut_zin_*: maps, tile types, CompressF'd colours, indices x 3), then the 1-D compressor."""
-    from oracle.pyoracle import yko_compress_f
+    from oracle.pyoracle import palette_remap, yko_compress_f
     n, h, w = planes.shape
     out = {}
     enc = OracleEncoder(planes)
     if n == 4:
         enc.mip_prefilter()
+    grad = []
     for sx, sy in PASSES:
-        enc.fitting_quad_smooth(sx, sy)
+        cnt, bm, rgb = enc.fitting_quad_smooth(sx, sy)
+        grad.append((sx, sy, cnt, bm, palette_decompress(enc.palette_compress(rgb), rgb.size, 250) if cnt else np.zeros(0, np.uint8)))
     for k, p in enumerate(patterns):
         enc.lut_load(p)
         if tables:
@@ -203,6 +206,7 @@ def oracle_lut_blobs(planes: np.ndarray, patterns, tables: bool = True) -> dict:
             zin.append((s[f"idx{bits}"].astype(np.uint16) * 3).astype(np.uint8).tobytes())
     for k, z in enumerate(zin):
         out[f"lut_zin_{k}"] = z
+    out["lut_file"] = enc.lut_file().tobytes()
     ends = []
     for p in range(3):
         enc.dynamic_tile_compressor(p)
@@ -211,6 +215,21 @@ def oracle_lut_blobs(planes: np.ndarray, patterns, tables: bool = True) -> dict:
     out["d1_pix"] = pix.tobytes()
     out["d1_type"] = typ.tobytes()
     out["d1_ends"] = np.array([e[0] for e in ends] + [e[1] for e in ends], dtype=np.int32).tobytes()
+    if w % 16 == 0 and h % 16 == 0:
+        # decode: gradient chunks, the '3DTL' chunk (Tile3D_* on the single-plane mask), mask split, '1DTL'
+        dec = OracleDecoder(w, h)
+        for sx, sy, cnt, bm, dq in grad:
+            if cnt:
+                dec.gradient(sx, sy, bm, dq)
+        used = dec.lut3d(enc.lut_file(), [s[f"map{k}"] for k in range(6)], s["tileType"], palette_remap(yko_compress_f(s["color"], 250), 250),
+                         [(s[f"idx{b}"].astype(np.uint16) * 3).astype(np.uint8) for b in (3, 4, 5, 6)])
+        out["lut_dec_consumed"] = used.astype(np.int32).tobytes()
+        out["lut_dec_planes"] = dec.planes().tobytes()
+        out["lut_dec_tile4x4"] = dec.tile4x4().tobytes()
+        dec.split_masks()
+        tp, pp = dec.decode_1d(typ, pix)
+        out["dec_1d_consumed"] = np.array([tp, pp], dtype=np.int32).tobytes()
+        out["dec_planes_full"] = dec.planes().tobytes()
     return out
 
 

@@ -123,3 +123,84 @@ def test_lut_search_matches_reference_fixture(hip, name):
     gpix, gtyp = hip.dynamic_tile_compressor()
     assert np.array_equal(gpix, ref["d1_pix"]) and np.array_equal(gtyp, ref["d1_type"])
     hip.lut_clear()
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from yaik_amd.decoder import HipTileDecoder
+    d = HipTileDecoder(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("name", sorted(LUT3D))
+def test_lut_decode_matches_reference_fixture(hip, dec, oracle_built, name):
+    """YAIK_AssignLUT + Tile3D_* + Decompress1D on the reference's own streams == the reference decoder's planes and mask."""
+    from oracle.pyoracle import palette_decompress, palette_remap
+    ref = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    planes, pats = LUT3D[name]()
+    n, h, w = planes.shape
+    ora = OracleEncoder(planes)
+    dec.begin(w, h)
+    for sx, sy in PASSES:
+        cnt, bm, rgb = ora.fitting_quad_smooth(sx, sy)
+        if cnt:
+            dec.decompress_gradient(sx, sy, bm, palette_decompress(ora.palette_compress(rgb), rgb.size, 250))
+    dec.assign_lut(ref["lut_file"])
+    zin = [ref[f"lut_zin_{k}"] for k in range(len([k for k in ref if k.startswith("lut_zin_")]))]
+    counts = np.frombuffer(ref["lut_counts"].tobytes(), np.int32).reshape(6, 6)[-1]
+    it = iter(zin[6:])
+    tiles = next(it).view(np.uint16) if counts[0] else np.zeros(0, np.uint16)
+    colors = palette_remap(next(it), 250) if counts[1] else np.zeros(0, np.uint8)
+    idx = [next(it) if counts[2 + f] else np.zeros(0, np.uint8) for f in range(4)]
+    used = dec.decompress_lut3d(zin[:6], tiles, colors, idx)
+    assert used.tolist() == np.frombuffer(ref["lut_dec_consumed"].tobytes(), np.int32).tolist()
+    assert np.array_equal(dec.planes().ravel(), ref["lut_dec_planes"])
+    assert np.array_equal(dec.tile4x4().ravel(), ref["lut_dec_tile4x4"])
+    dec.decompress_1d(ref["d1_type"], ref["d1_pix"])
+    assert np.array_equal(dec.planes().ravel(), ref["dec_planes_full"])
+
+
+@pytest.mark.parametrize("w,h,seed", [(128, 128, 21), (256, 192, 22), (512, 512, 23)])
+def test_lut_round_trip_on_gpu(hip, dec, oracle_built, w, h, seed):
+    """GPU encode (gradient passes, 3-D LUT search, 1-D path) -> GPU decode == the oracle's decode of the same streams; PSNR stated."""
+    from oracle.pyoracle import OracleDecoder, detile, palette_remap, yko_compress_f
+    pats = bank_patterns()
+    planes = lut_image(w, h, pats, seed)
+    ora = OracleEncoder(planes)
+    hip.lut_clear()
+    for p in pats:
+        hip.lut_load(p); ora.lut_load(p)
+    hip.set_image(planes)
+    hip.encode(3, False, False)
+    od = OracleDecoder(w, h)
+    dec.begin(w, h)
+    for i, (sx, sy) in enumerate(PASSES):
+        bm, rgb = hip.gradient_bitmap(i), hip.gradient_corners(i)
+        if rgb.size:
+            dq = palette_remap(rgb, 250)
+            od.gradient(sx, sy, bm, dq); dec.decompress_gradient(sx, sy, bm, dq)
+    hip.lut_start()
+    for sx, sy in LUT_PASSES:
+        hip.lut_search(sx, sy)
+    s = hip.lut_streams()
+    assert s["tileType"].size > 0
+    lut_file = ora.lut_file()
+    colors = palette_remap(yko_compress_f(s["color"], 250), 250)
+    idx = [(s[f"idx{b}"].astype(np.uint16) * 3).astype(np.uint8) for b in (3, 4, 5, 6)]
+    maps = [s[f"map{k}"] for k in range(6)]
+    want_used = od.lut3d(lut_file, maps, s["tileType"], colors, idx)
+    dec.assign_lut(lut_file)
+    used = dec.decompress_lut3d(maps, s["tileType"], colors, idx)
+    assert used.tolist() == want_used.tolist() == [s["tileType"].size * 2, s["color"].size] + [i.size for i in idx]
+    assert np.array_equal(dec.planes(), od.planes()) and np.array_equal(dec.tile4x4().ravel(), od.tile4x4().ravel())
+    pix, typ = hip.dynamic_tile_compressor()
+    od.split_masks()
+    assert od.decode_1d(typ, pix) == (typ.size, pix.size)
+    dec.decompress_1d(typ, pix)
+    gp = dec.planes()
+    assert np.array_equal(gp, od.planes())
+    rec = np.stack([detile(gp[c], w, h) for c in range(3)]).astype(np.int64)
+    mse = float(np.mean((rec - planes) ** 2))
+    assert 10 * np.log10(255.0 ** 2 / mse) > 35.0
+    hip.lut_clear()

@@ -99,6 +99,8 @@ SIGNATURES = {
     "yk_decode_tile4x4_planes": (C.c_int, [vp, vp, sz]),
     "yk_decode_gradient_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz]),
     "yk_decode_split_masks": (C.c_int, [vp]),
+    "yk_decode_assign_lut": (C.c_int, [vp, vp, sz]),
+    "yk_decode_lut3d": (C.c_int, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
     "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),

@@ -148,6 +148,7 @@ void yk_destroy(yk_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     yk_free_image(c);
     yk_lut_destroy(c);
+    yk_lut_dec_destroy(c);
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);

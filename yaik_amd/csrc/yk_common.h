@@ -105,6 +105,7 @@ struct yk_ctx {
     uint32_t* ppScratch = nullptr; size_t ppScratchElems = 0, ppBitmapCap = 0; int ppAccepted = 0; bool ppActive = false;
     // (f)4 3-D LUT tiles (yk_lut3d.hip): pattern bank + the streams StartCorrelationSearch allocates
     struct YkLutState* lut = nullptr;
+    struct YkLutDecState* lutDec = nullptr;      // decoder: the per-orientation tables YAIK_AssignLUT lays out
     // live 1-D range path (a15)
     uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
     uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;
@@ -146,6 +147,7 @@ int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
 int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch = false);
 int yk_launch_pack(yk_ctx* c, bool batch = false);
 int yk_launch_corners(yk_ctx* c);
+void yk_lut_dec_destroy(yk_ctx* c);
 void yk_lut_destroy(yk_ctx* c);                          // frees the 3-D LUT bank and streams (yk_lut3d.hip)
 int yk_pp_activate(yk_ctx* c);                           // per-plane coverage / corner flags for the passes behind the RGB passes
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P);

@@ -468,3 +468,190 @@ int yk_lut_stream(yk_ctx* c, int which, uint8_t* hostOut, size_t cap, size_t* nB
 }
 
 }  // extern "C"
+
+// ==== decoder side =================================================================================================================
+// YAIK_AssignLUT (decoder/YAIK_API.cpp:133-415) and Tile3D_16x8 .. Tile3D_4x4 (decoder/YAIK_3DTile.cpp:244-2140).  The reference walks the
+// tile maps sequentially, popping 6 colour bytes, a tile word and one pre-multiplied index per still unmarked pixel per tile.  Here a pass
+// is three small launches: rank of every set map bit (= position in the tile / colour streams), index bytes per depth of every tile from
+// its tile word and the tile4x4Mask state (-> offsets in the four index streams), then the fill.  Tiles of a pass are disjoint.
+struct YkLutDecState { uint8_t* tbl[4] = {}; int nPat = 0; };
+
+__device__ __forceinline__ bool yk_dl_tile(const uint32_t* __restrict__ map, size_t nSlots, size_t pos, const LutGeo& g, int w, int h, int& x0, int& y0) {
+    if (pos >= nSlots || !((map[pos >> 5] >> (pos & 31)) & 1u)) return false;
+    const uint32_t blk = (uint32_t)pos / (uint32_t)g.bitCount, t = (uint32_t)pos % (uint32_t)g.bitCount;
+    x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(t % (uint32_t)g.tilesPerRow) * (1 << g.sx);
+    y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(t / (uint32_t)g.tilesPerRow) * (1 << g.sy);
+    return x0 < w && y0 < h;
+}
+__device__ __forceinline__ bool yk_dl_marked(const uint8_t* __restrict__ tile4, int stride4, int gx, int gy) {
+    const int cx = gx >> 2, cy = gy >> 2;
+    return (tile4[(cx >> 2) + (cy >> 1) * stride4] >> ((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1))) & 1;
+}
+__global__ __launch_bounds__(1024) void yk_dl_rank_kernel(const uint32_t* __restrict__ map, size_t nSlots, LutGeo g, int w, int h, uint32_t* __restrict__ blockSums) {
+    __shared__ uint32_t s_tmp[32];
+    int x0, y0; uint32_t tot;
+    yk_block_exscan(yk_dl_tile(map, nSlots, (size_t)blockIdx.x * 1024 + threadIdx.x, g, w, h, x0, y0) ? 1u : 0u, s_tmp, &tot);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+}
+// FILL = false: index bytes per depth and workgroup; FILL = true: decode
+template <bool FILL>
+__global__ __launch_bounds__(1024) void yk_dl_tile_kernel(const uint32_t* __restrict__ map, size_t nSlots, LutGeo g, int w, int h, const uint32_t* __restrict__ rankBase, size_t nb,
+                                                          uint32_t* __restrict__ byteSums /*[4][nb]*/, const uint16_t* __restrict__ tiles, unsigned long long tileBase, unsigned long long nTiles,
+                                                          const uint8_t* __restrict__ colors, const uint8_t* const __restrict__ idx0, const uint8_t* const __restrict__ idx1,
+                                                          const uint8_t* const __restrict__ idx2, const uint8_t* const __restrict__ idx3, unsigned long long ib0, unsigned long long ib1,
+                                                          unsigned long long ib2, unsigned long long ib3, const uint8_t* const __restrict__ t0, const uint8_t* const __restrict__ t1,
+                                                          const uint8_t* const __restrict__ t2, const uint8_t* const __restrict__ t3, int nPat,
+                                                          uint8_t* __restrict__ planes, size_t planeSize, int tileW, uint8_t* __restrict__ tile4, int stride4) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t pos = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    int x0 = 0, y0 = 0;
+    const bool set = yk_dl_tile(map, nSlots, pos, g, w, h, x0, y0);
+    uint32_t tot;
+    const uint32_t rank = rankBase[blockIdx.x] + yk_block_exscan(set ? 1u : 0u, s_tmp, &tot);
+    const unsigned long long ti = tileBase + rank;
+    const bool live = set && ti < nTiles;                                       // the reference trusts the counts of the header (its TODOs at :1079, :1108)
+    const int TX = 1 << g.sx, TY = 1 << g.sy;
+    int fmt = 0, tile = 0; uint32_t nbytes = 0;
+    if (live) {
+        tile = tiles[ti]; fmt = (tile >> 14) & 3;
+        for (int cy = 0; cy < TY; cy += 4) for (int cx = 0; cx < TX; cx += 4) if (!yk_dl_marked(tile4, stride4, x0 + cx, y0 + cy)) nbytes += 16;
+    }
+    uint32_t off[4];
+    for (int f = 0; f < 4; f++) {
+        const uint32_t e = yk_block_exscan((live && fmt == f) ? nbytes : 0u, s_tmp, &tot);
+        if (!FILL) { if (threadIdx.x == 0) byteSums[f * nb + blockIdx.x] = tot; }
+        else off[f] = byteSums[f * nb + blockIdx.x] + e;
+    }
+    if (!FILL || !live) return;
+    const uint8_t* const idxS[4] = { idx0, idx1, idx2, idx3 };
+    const unsigned long long ib[4] = { ib0, ib1, ib2, ib3 };
+    const uint8_t* const tblS[4] = { t0, t1, t2, t3 };
+    const uint8_t* __restrict__ src = idxS[fmt] + ib[fmt] + off[fmt];
+    const uint8_t* __restrict__ RGB = colors + ti * 6;
+    const int len = 8 << fmt, pattern = (tile >> 6) & 255, orient = tile & 63;
+    const uint8_t* __restrict__ lut = tblS[fmt] + ((size_t)pattern * 64 + orient) * len * 3;     // [(tile & 0x3FFF) * 3] << (3 + format), :330
+    const bool inTable = pattern < nPat;
+    const int diff[3] = { RGB[3] - RGB[0], RGB[4] - RGB[1], RGB[5] - RGB[2] };
+    const int xCount = TX > 8 ? 2 : 1, lX = TX > 8 ? 8 : TX;
+    int n = 0;
+    for (int xa = 0; xa < xCount; xa++) for (int y = 0; y < TY; y++) for (int x = 0; x < lX; x++) {
+        const int gx = x0 + x + xa * 8, gy = y0 + y;
+        if (yk_dl_marked(tile4, stride4, gx, gy)) continue;
+        const int e3 = src[n++];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int v = (inTable && e3 + c < len * 3) ? lut[e3 + c] : 251;    // beyond the loaded bank the reference reads its filler / unset memory
+            planes[(size_t)c * planeSize + ((size_t)(gy >> 3) * tileW + (gx >> 3)) * 64 + (gy & 7) * 8 + (gx & 7)] = (uint8_t)(RGB[c] + ((diff[c] * v) >> 7));
+        }
+    }
+}
+// the cells of the pass's tiles are marked after the fill (a separate launch: the fill reads the mask of its own cells while it runs)
+__global__ __launch_bounds__(256) void yk_dl_mark_kernel(const uint32_t* __restrict__ map, size_t nSlots, LutGeo g, int w, int h, uint32_t* __restrict__ tile4w, int stride4) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int x0, y0;
+    if (!yk_dl_tile(map, nSlots, pos, g, w, h, x0, y0)) return;
+    for (int cy = y0 >> 2; cy < (y0 + (1 << g.sy)) >> 2; cy++) for (int cx = x0 >> 2; cx < (x0 + (1 << g.sx)) >> 2; cx++) {
+        const size_t byteI = (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
+        const int bit = (((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1);
+        atomicOr(&tile4w[byteI >> 2], 1u << (bit + 8 * (byteI & 3)));
+    }
+}
+
+void yk_lut_dec_destroy(yk_ctx* c) {
+    if (!c->lutDec) return;
+    for (auto& p : c->lutDec->tbl) if (p) (void)hipFree(p);
+    delete c->lutDec; c->lutDec = nullptr;
+}
+
+extern "C" {
+
+int yk_decode_assign_lut(yk_ctx* c, const uint8_t* lutFile, size_t lutBytes) {
+    if (!c || !lutFile) return YK_ERR_BAD_ARG;
+    if (lutBytes < 8 || lutFile[0] != 'L' || lutFile[1] != 'U' || lutFile[2] != 'L') return yk_fail(c, YK_ERR_BAD_ARG, "not a 3-D LUT file ('LUL')");       // YAIK_INVALID_LUT
+    const int nPat = lutFile[5] + 1;
+    if (lutBytes != 8 + (size_t)nPat * 3 * (64 + 32 + 16 + 8)) return yk_fail(c, YK_ERR_BAD_ARG, "LUT file size does not match its entry count");
+    YK_HIP(c, hipSetDevice(c->device));
+    yk_lut_dec_destroy(c);
+    c->lutDec = new YkLutDecState(); c->lutDec->nPat = nPat;
+    static const int axis[6][3] = { {0,1,2}, {0,2,1}, {1,0,2}, {1,2,0}, {2,0,1}, {2,1,0} };       // X, X[ZY], [YX]Z, YZX, ZXY, ZYX (:297-337)
+    const uint8_t* stream = lutFile + 8;
+    for (int bit = 3; bit <= 6; bit++) {
+        const int len = 1 << bit;
+        std::vector<uint8_t> T((size_t)nPat * 64 * len * 3, 251);              // slots 48..63 of every pattern stay filler (:400-404)
+        for (int e = 0; e < nPat; e++) {
+            const uint8_t* o[3] = { stream, stream + len, stream + 2 * len };
+            uint8_t* fill = T.data() + (size_t)e * 64 * len * 3;
+            for (int pat = 0; pat < 6; pat++) for (int flip = 0; flip < 8; flip++) for (int i = 0; i < len; i++) for (int k = 0; k < 3; k++) {
+                const uint8_t v = o[axis[pat][k]][i];
+                *fill++ = ((flip >> k) & 1) ? (uint8_t)(128 - v) : v;
+            }
+            stream += len * 3;
+        }
+        YK_HIP(c, hipMalloc(&c->lutDec->tbl[bit - 3], T.size() + 16));
+        YK_HIP(c, hipMemcpy(c->lutDec->tbl[bit - 3], T.data(), T.size(), hipMemcpyHostToDevice));
+    }
+    return YK_OK;
+}
+
+int yk_decode_lut3d(yk_ctx* c, const uint8_t* const maps[6], const size_t mapBytes[6], const uint16_t* tiles, size_t nTiles, const uint8_t* colors,
+                    const uint8_t* const idx[4], const size_t idxBytes[4], size_t consumed[6]) {
+    if (!c || !maps || !mapBytes || !idx || !idxBytes) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    if (!c->lutDec) return yk_fail(c, YK_ERR_STATE, "yk_decode_assign_lut first");
+    if (c->dSplit) return yk_fail(c, YK_ERR_STATE, "a '3DTL' chunk comes before the masks are split ('1DTL', plane-subset chunks)");
+    YK_HIP(c, hipSetDevice(c->device));
+    const int w = c->dw, h = c->dh;
+    static const int sz[6][2] = { {4,3}, {3,4}, {3,3}, {3,2}, {2,3}, {2,2} };
+    uint16_t* dTiles = nullptr; uint8_t* dColors = nullptr; uint8_t* dIdx[4] = {}; uint32_t* dMap = nullptr; uint32_t* sums = nullptr;
+    auto freeAll = [&]() { (void)hipFree(dTiles); (void)hipFree(dColors); for (auto p : dIdx) (void)hipFree(p); (void)hipFree(dMap); (void)hipFree(sums); };
+    size_t maxMap = 0; for (int k = 0; k < 6; k++) maxMap = mapBytes[k] > maxMap ? mapBytes[k] : maxMap;
+    const size_t maxSlots = maxMap * 8, maxNb = (maxSlots + 1023) / 1024 + 1;
+    hipError_t e = hipMalloc(&dTiles, nTiles * 2 + 64);
+    if (e == hipSuccess) e = hipMalloc(&dColors, nTiles * 6 + 64);
+    for (int f = 0; f < 4 && e == hipSuccess; f++) e = hipMalloc(&dIdx[f], idxBytes[f] + 256);
+    if (e == hipSuccess) e = hipMalloc(&dMap, maxMap + 64);
+    if (e == hipSuccess) e = hipMalloc(&sums, (5 * maxNb + 16) * sizeof(uint32_t));
+    if (e == hipSuccess && nTiles) e = hipMemcpyAsync(dTiles, tiles, nTiles * 2, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nTiles) e = hipMemcpyAsync(dColors, colors, nTiles * 6, hipMemcpyHostToDevice, c->stream);
+    for (int f = 0; f < 4 && e == hipSuccess; f++) {
+        e = hipMemsetAsync(dIdx[f], 0, idxBytes[f] + 256, c->stream);
+        if (e == hipSuccess && idxBytes[f]) e = hipMemcpyAsync(dIdx[f], idx[f], idxBytes[f], hipMemcpyHostToDevice, c->stream);
+    }
+    unsigned long long tileBase = 0, ib[4] = { 0, 0, 0, 0 };
+    for (int k = 0; k < 6 && e == hipSuccess; k++) {
+        if (!maps[k] || !mapBytes[k]) continue;
+        const LutGeo g = yk_lut_geo(sz[k][0], sz[k][1], w);
+        size_t nSlots = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount;
+        if (nSlots > mapBytes[k] * 8) nSlots = mapBytes[k] * 8;
+        const size_t nb = (nSlots + 1023) / 1024;
+        e = hipMemsetAsync(dMap, 0, maxMap + 64, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dMap, maps[k], mapBytes[k], hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) break;
+        uint32_t* rankBase = sums; uint32_t* byteSums = sums + maxNb; uint32_t* totals = sums + 5 * maxNb;
+        hipLaunchKernelGGL(yk_dl_rank_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, dMap, nSlots, g, w, h, rankBase);
+        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, rankBase, (int)nb, totals);
+#define YK_DL_ARGS dMap, nSlots, g, w, h, rankBase, nb, byteSums, dTiles, tileBase, (unsigned long long)nTiles, dColors, dIdx[0], dIdx[1], dIdx[2], dIdx[3], ib[0], ib[1], ib[2], ib[3], \
+                   c->lutDec->tbl[0], c->lutDec->tbl[1], c->lutDec->tbl[2], c->lutDec->tbl[3], c->lutDec->nPat, c->dPlanes, c->dPlaneSize, w >> 3, c->dTile4, (w + 15) >> 4
+        hipLaunchKernelGGL(yk_dl_tile_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, YK_DL_ARGS);
+        for (int f = 0; f < 4; f++) hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, byteSums + f * nb, (int)nb, totals + 1 + f);
+        hipLaunchKernelGGL(yk_dl_tile_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, YK_DL_ARGS);
+#undef YK_DL_ARGS
+        hipLaunchKernelGGL(yk_dl_mark_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, c->stream, dMap, nSlots, g, w, h, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
+        e = hipGetLastError();
+        uint32_t tot[5] = {};
+        if (e == hipSuccess) e = hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        unsigned long long used = tot[0];
+        if (tileBase + used > nTiles) used = nTiles - tileBase;
+        tileBase += used;
+        for (int f = 0; f < 4; f++) ib[f] += tot[1 + f];
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    freeAll();
+    if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "3-D LUT decode", e);
+    for (int f = 0; f < 4; f++) if (ib[f] > idxBytes[f]) return yk_fail(c, YK_ERR_RANGE, "index stream shorter than the tile maps need");
+    if (consumed) { consumed[0] = (size_t)tileBase * 2; consumed[1] = (size_t)tileBase * 6; for (int f = 0; f < 4; f++) consumed[2 + f] = (size_t)ib[f]; }
+    return YK_OK;
+}
+
+}  // extern "C"

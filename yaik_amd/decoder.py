@@ -47,6 +47,24 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_decode_gradient_planes(self._h, plane_bit, int(consistent_marks), bitmap.ctypes.data, bitmap.size,
                                                       rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size))
 
+    def assign_lut(self, lut_file: np.ndarray) -> None:
+        """YAIK_AssignLUT: the decoder's 3-D LUT file ('LUL0')."""
+        lf = np.ascontiguousarray(lut_file, dtype=np.uint8)
+        _chk(self._h, lib().yk_decode_assign_lut(self._h, lf.ctypes.data, lf.size))
+
+    def decompress_lut3d(self, maps, tiles: np.ndarray, colors_dq: np.ndarray, idx) -> np.ndarray:
+        """The '3DTL' chunk: Tile3D_16x8 .. Tile3D_4x4 on its streams (see yk_decode_lut3d).  Returns the bytes consumed per stream."""
+        mp = [np.ascontiguousarray(m, dtype=np.uint8) for m in maps]
+        ix = [np.ascontiguousarray(i, dtype=np.uint8) for i in idx]
+        t = np.ascontiguousarray(tiles, dtype=np.uint16); cdq = np.ascontiguousarray(colors_dq, dtype=np.uint8)
+        mptr = (C.c_void_p * 6)(*[m.ctypes.data if m.size else None for m in mp])
+        msz = (C.c_size_t * 6)(*[m.size for m in mp])
+        iptr = (C.c_void_p * 4)(*[i.ctypes.data if i.size else None for i in ix])
+        isz = (C.c_size_t * 4)(*[i.size for i in ix])
+        used = (C.c_size_t * 6)()
+        _chk(self._h, lib().yk_decode_lut3d(self._h, mptr, msz, t.ctypes.data if t.size else None, t.size, cdq.ctypes.data if cdq.size else None, iptr, isz, used))
+        return np.array(list(used), dtype=np.int64)
+
     def decompress_1d(self, type_stream: np.ndarray, pix_stream: np.ndarray, compression_range: int = 15):
         t = np.ascontiguousarray(type_stream, dtype=np.uint8)
         p = np.ascontiguousarray(pix_stream, dtype=np.uint8)
