@@ -96,3 +96,49 @@ def test_cpp_partial_plane_passes(oracle_built, case):
         assert dec.decode_1d(typ, pix) == (typ.size, pix.size)
         assert got["yaik_planes_tiled_1"] == dec.planes().tobytes()
         assert len(got["yaik_planes_tiled_0"]) == len(got["yaik_planes_tiled_1"])      # reference-exact marks: decodes, but desynchronised
+
+
+@pytest.mark.parametrize("w,h,seed", [(128, 128, 31), (256, 192, 32)])
+def test_cpp_lut3d_surface(oracle_built, w, h, seed):
+    """(f)4 through the C++ mirror: Load3DPattern from bank files, StartCorrelationSearch, Correlation3DSearch x6, EndCorrelationSearch ('3DTL'),
+    the 1-D compressor behind them, LutFile -> YAIK_AssignLUT -> YAIK_DecodeImage; decoded planes == the oracle's decode of the oracle's streams."""
+    from oracle.pyoracle import PASSES, OracleDecoder, OracleEncoder, palette_decompress, palette_remap, yko_compress_f
+    from tests.blobs import LUT_PASSES
+    from tests.lutbank import bank_bytes, bank_patterns, lut_image
+    pats = bank_patterns()
+    planes = lut_image(w, h, pats, seed)
+    with tempfile.TemporaryDirectory() as d:
+        fb = os.path.join(d, "bank.bin")
+        with open(fb, "wb") as f:
+            f.write(bank_bytes(pats))
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.blobs")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<3i", w, h, 3)); f.write(np.ascontiguousarray(planes, np.int32).tobytes())
+        if not os.path.exists(DRIVER):
+            subprocess.run(["make", "-C", os.path.dirname(DRIVER)], check=True)
+        subprocess.run([DRIVER, fin, fout, "lut", fb], check=True)
+        got = parse_blobs(fout)
+    ora = OracleEncoder(planes)
+    od = OracleDecoder(w, h)
+    for sx, sy in PASSES:
+        cnt, bm, rgb = ora.fitting_quad_smooth(sx, sy)
+        if cnt:
+            od.gradient(sx, sy, bm, palette_decompress(ora.palette_compress(rgb), rgb.size, 250))
+    for p in pats:
+        ora.lut_load(p)
+    ora.lut_start()
+    matched = [ora.lut_search(sx, sy) for sx, sy in LUT_PASSES]
+    assert np.frombuffer(got["lut_matched"], np.int32).tolist() == matched and sum(matched) > 0
+    assert got["lut_file"] == ora.lut_file().tobytes()
+    s = ora.lut_streams()
+    od.lut3d(ora.lut_file(), [s[f"map{k}"] for k in range(6)], s["tileType"], palette_remap(yko_compress_f(s["color"], 250), 250),
+             [(s[f"idx{b}"].astype(np.uint16) * 3).astype(np.uint8) for b in (3, 4, 5, 6)])
+    for p in range(3):
+        ora.dynamic_tile_compressor(p)
+    pix, typ = ora.streams_1d()
+    assert got["d1_pix"] == pix.tobytes() and got["d1_type"] == typ.tobytes()
+    od.split_masks()
+    assert od.decode_1d(typ, pix) == (typ.size, pix.size)
+    codes = np.frombuffer(got["yaik_lut_codes"], np.int32).tolist()
+    assert codes[0] != 0 and codes[1] == 0, codes                # refused without the LUT, decoded with it
+    assert got["yaik_planes_tiled"] == od.planes().tobytes()

@@ -10,6 +10,7 @@
 #include <thread>
 #include "../../include/yaik_hip.h"
 #include "chunks.h"
+#include "yaik_format.h"
 #include "palette.h"
 #include "zstd_dl.h"
 
@@ -20,7 +21,7 @@ EncoderContext::EncoderContext()
       mipMapTileSize(16), boundX0(0), boundY0(0), boundX1(0), boundY1(0), remainingPixels(0),
       dumpImage(false), evaluateLUT(false), evaluateLUT2D(false), outFile(nullptr), fileOutSize(0), device(0),
       original(nullptr), ctx(nullptr), bound(false), alphaDone(false), encoded(false), enc3(false), encDst(false), oneDReady(false),
-      encReject(3), nextPass(0), nNibbles(0), cursor1d(0), mipHasChunk(false) {}
+      encReject(3), nextPass(0), nNibbles(0), cursor1d(0), mipHasChunk(false), lutMatched(0) { correlationPatternCount3D = 0; }
 
 EncoderContext::~EncoderContext() { Release(); }
 
@@ -193,6 +194,78 @@ u8* EncoderContext::DynamicTileCompressor(u8* stream, Plane* src, Plane* /*map*/
     const size_t from = p ? pixEnd[p - 1] : 0, per = pixEnd[p] - from;
     memcpy(stream, pix1d.data() + from, per);
     return stream + per;
+}
+
+// ---- (f)4 3-D LUT tiles ----------------------------------------------------------------------------------------------------------
+void EncoderContext::Load3DPattern(const char* fileName) {
+    FILE* f = fopen(fileName, "rb");
+    if (!f) return;                                                        // a missing bank file is skipped silently (:7853-7854)
+    u8 count = 0, r[256], g[256], b[256];
+    bool ok = fread(&count, 1, 1, f) == 1 && fread(r, 1, count, f) == count && fread(g, 1, count, f) == count && fread(b, 1, count, f) == count;
+    fclose(f);
+    if (!ok) { fail("Load3DPattern: short file"); return; }
+    if (!ctx) { fail("Load3DPattern: SetImageToEncode first (the bank lives on the GPU handle)"); return; }
+    int idx = -1;
+    if (yk_lut_load_pattern(ctx, r, g, b, count, &idx) != YK_OK) { fail("Load3DPattern: pattern refused (1..64 points of 6 bits, at most 64 patterns)"); return; }
+    std::vector<u8> p((size_t)count * 3);
+    for (int n = 0; n < count; n++) { p[n * 3] = r[n]; p[n * 3 + 1] = g[n]; p[n * 3 + 2] = b[n]; }
+    lutPatterns.push_back(p);
+    correlationPatternCount3D = idx + 1;
+}
+
+bool EncoderContext::Save3DLutFile(const char* fileName) {
+    if (!ctx || correlationPatternCount3D == 0) return fail("Save3DLutFile: no pattern loaded");
+    std::vector<u8> file(sizeof(yaikfmt::LUTHeader) + (size_t)(64 + 32 + 16 + 8) * 3 * correlationPatternCount3D, 0);
+    yaikfmt::LUTHeader hd; memset(&hd, 0, sizeof hd);
+    hd.lutH[0] = 'L'; hd.lutH[1] = 'U'; hd.lutH[2] = 'L'; hd.lutH[3] = '0'; hd.entryCount = (u8)(correlationPatternCount3D - 1); hd.padding_extension[0] = 1;
+    memcpy(file.data(), &hd, sizeof hd);
+    std::vector<int16_t> fac((size_t)correlationPatternCount3D * 4 * 3 * 64);
+    for (int e = 0; e < correlationPatternCount3D; e++)
+        if (yk_lut_pattern_tables(ctx, e, fac.data() + (size_t)e * 4 * 3 * 64, nullptr, nullptr) != YK_OK) return fail("yk_lut_pattern_tables");
+    u8* w = file.data() + sizeof hd;
+    for (int depth = 3; depth >= 0; depth--)                               // 3, 4, 5, 6 bit (BinarySave3D per depth and pattern, :7836-7841)
+        for (int e = 0; e < correlationPatternCount3D; e++)
+            for (int c = 0; c < 3; c++) for (int m = 0; m < (64 >> depth); m++) *w++ = (u8)fac[(((size_t)e * 4 + depth) * 3 + c) * 64 + m];
+    FILE* f = fopen(fileName, "wb");
+    if (!f) return fail("Save3DLutFile: cannot open the file");
+    const bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    fclose(f);
+    return ok || fail("Save3DLutFile: fwrite");
+}
+
+void EncoderContext::StartCorrelationSearch(bool is3D) {
+    if (!is3D) { fail("StartCorrelationSearch: the 2-D correlation mode is deprecated in the reference and not on this path"); return; }
+    if (!bound) { fail("StartCorrelationSearch: SetImageToEncode first"); return; }
+    if (!encoded || nextPass != 7) { fail("StartCorrelationSearch: the 3-D LUT search follows the seven RGB gradient passes"); return; }
+    if (yk_lut_start(ctx) != YK_OK) { fail("yk_lut_start"); return; }
+    oneDReady = false;
+}
+
+void EncoderContext::Correlation3DSearch(Image* input, Image* /*output*/, int tileShiftX, int tileShiftY) {
+    if (!bound || input != original) { fail("Correlation3DSearch: input must be the image to encode"); return; }
+    lutMatched = 0;
+    if (yk_lut_search(ctx, tileShiftX, tileShiftY, &lutMatched) != YK_OK) { fail("yk_lut_search"); return; }
+    oneDReady = false;
+}
+
+void EncoderContext::EndCorrelationSearch(bool is3D, u8 component) {
+    if (!is3D || !bound) { fail("EndCorrelationSearch: 3-D search on a bound image only"); return; }
+    std::vector<u8> buf[12];
+    for (int which = 0; which < 12; which++) {
+        size_t n = 0;
+        if (yk_lut_stream(ctx, which, nullptr, 0, &n) != YK_OK) { fail("yk_lut_stream"); return; }
+        buf[which].assign(n, 0);
+        if (n && yk_lut_stream(ctx, which, buf[which].data(), n, nullptr) != YK_OK) { fail("yk_lut_stream"); return; }
+    }
+    if (!outFile) return;
+    yaikchunk::Tile3DStreams st;
+    for (int k = 0; k < 6; k++) { st.map[k] = buf[6 + k].data(); st.mapBytes[k] = buf[6 + k].size(); }
+    st.tileType = reinterpret_cast<const u16*>(buf[0].data()); st.nTiles = buf[0].size() / 2; st.color = buf[1].data();
+    for (int b = 0; b < 4; b++) { st.idx[b] = buf[2 + b].data(); st.nIdx[b] = buf[2 + b].size(); }
+    std::string e;
+    const long before = ftell(outFile);
+    if (!yaikchunk::writeTile3D(outFile, st, colorCompressionLUT3D, component, e)) { fail(("EndCorrelationSearch: " + e).c_str()); return; }
+    fileOutSize += (int)(ftell(outFile) - before);
 }
 
 void EncoderContext::GenerateDynamicTileChunk(u8* stream, int sizeStream) {

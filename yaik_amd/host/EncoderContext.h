@@ -41,6 +41,14 @@ public:
                            int tileBitSizeX, int tileBitSizeY);                           // :3710, returns TileDone
     int  DynamicTileEncode(bool mode3BitOnly, Plane* plane, Plane* dst, bool isCo, bool isCg, bool isHalfX, bool isHalfY);   // :4365
     u8*  DynamicTileCompressor(u8* stream, Plane* src, Plane* map, Plane* debug);         // :8398, returns the advanced cursor
+    // (f)4 3-D LUT tiles, where Convert() runs them (:9117-9218): after the gradient passes, before the 1-D compressor
+    void Load3DPattern(const char* fileName);                                             // :7851, one 'Bank3D' .lut file (u8 count, r[], g[], b[])
+    bool Save3DLutFile(const char* fileName);                                             // the decoder's 'LUL0' file RegisterAndCreate3DLut writes (:7820-7847)
+    void StartCorrelationSearch(bool is3D);                                               // :7316
+    void Correlation3DSearch(Image* input, Image* output, int tileShiftX, int tileShiftY);// :6245
+    void EndCorrelationSearch(bool is3D, u8 component);                                   // :7366, appends the '3DTL' chunk to outFile
+    int  correlationPatternCount3D;
+    int  LastCorrelationMatches() const { return lutMatched; }                            // "MATCHED TILE" of the last Correlation3DSearch
     void GenerateDynamicTileChunk(u8* stream, int sizeStream);                            // :8524, '1DTL' chunk of the three planes' streams
     // The chunk sequence of Convert() restricted to this path (:9007-9016, :9057-9093, :9451-9470, :9779-9781): file header,
     // ['MIPM' for RGBA], 7x 'GTIL', '1DTL', terminator — a stream the reference's YAIK_DecodeImage accepts.  Takes no ownership of f.
@@ -84,5 +92,7 @@ private:
     std::vector<u16> tileDefs;
     size_t nNibbles, cursor1d;
     bool mipHasChunk;
+    int lutMatched;
+    std::vector<std::vector<u8>> lutPatterns;          // as loaded (count x 3, interleaved): the factor tables of the LUT file come from them
     std::string err;
 };

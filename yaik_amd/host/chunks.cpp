@@ -130,4 +130,41 @@ bool writeTile1D(FILE* f, const u8* pix, size_t pixBytes, const u8* type, size_t
     return emitTile1D(f, pixBytes, typeBytes, zPix, zType, compressionColor, compressionRange, err);
 }
 
+bool writeTile3D(FILE* f, const Tile3DStreams& st, int colorCompression, int component, std::string& err) {
+    HeaderTile3D h; memset(&h, 0, sizeof h);
+    for (int k = 0; k < 6; k++) if (st.mapBytes[k] > 65535) { err = "'3DTL' keeps tile-map sizes in 16 bits (HeaderTile3D, YAIK_private.h:316-328): image too large for this chunk"; return false; }
+    std::vector<u8> zMap[6], zType, zColor, zIdx[4];
+    for (int k = 0; k < 6; k++) if (!zcompress(st.map[k], st.mapBytes[k], 18, zMap[k], err)) return false;
+    h.component = (u8)component;
+    // header fields in the reference's naming; the MAP ORDER in the payload is 16x8, 8x16, 8x8, 8x4, 4x8, 4x4 (:7651-7662)
+    h.sizeT16_8Map = (u16)st.mapBytes[0]; h.sizeT16_8MapCmp = (u16)zMap[0].size();
+    h.sizeT8_16Map = (u16)st.mapBytes[1]; h.sizeT8_16MapCmp = (u16)zMap[1].size();
+    h.sizeT8_8Map = (u16)st.mapBytes[2]; h.sizeT8_8MapCmp = (u16)zMap[2].size();
+    h.sizeT8_4Map = (u16)st.mapBytes[3]; h.sizeT8_4MapCmp = (u16)zMap[3].size();
+    h.sizeT4_8Map = (u16)st.mapBytes[4]; h.sizeT4_8MapCmp = (u16)zMap[4].size();
+    h.sizeT4_4Map = (u16)st.mapBytes[5]; h.sizeT4_4MapCmp = (u16)zMap[5].size();
+    h.streamTypeCnt = (u32)st.nTiles; h.streamColorCnt = (u32)st.nTiles * 6;
+    if (st.nTiles) {
+        if (!zcompress(st.tileType, st.nTiles * 2, 18, zType, err)) return false;
+        std::vector<u8> col(st.color, st.color + st.nTiles * 6);
+        for (auto& v : col) v = (u8)((v * colorCompression + 127) / 255);                // CompressF (:7494-7497)
+        if (!zcompress(col.data(), col.size(), 18, zColor, err)) return false;
+        h.compressionRateColor = (u8)colorCompression;
+    }
+    h.comprTypeSize = (u32)zType.size(); h.comprColorSize = (u32)zColor.size();
+    u32* cnt[4] = { &h.stream3BitCnt, &h.stream4BitCnt, &h.stream5BitCnt, &h.stream6BitCnt };
+    u32* cmp[4] = { &h.compr3BitSize, &h.compr4BitSize, &h.compr5BitSize, &h.compr6BitSize };
+    for (int b = 0; b < 4; b++) {
+        *cnt[b] = (u32)st.nIdx[b];
+        if (st.nIdx[b]) {
+            std::vector<u8> x3(st.idx[b], st.idx[b] + st.nIdx[b]);
+            for (auto& v : x3) v = (u8)(v * 3);                                           // index -> interleaved entry offset (:7526-7529)
+            if (!zcompress(x3.data(), x3.size(), 18, zIdx[b], err)) return false;
+        }
+        *cmp[b] = (u32)zIdx[b].size();
+    }
+    if (!putChunk(f, TAG_TILE3D, &h, sizeof h, { &zIdx[0], &zIdx[1], &zIdx[2], &zIdx[3], &zType, &zColor, &zMap[0], &zMap[1], &zMap[2], &zMap[3], &zMap[4], &zMap[5] })) { err = "fwrite"; return false; }
+    return true;
+}
+
 }  // namespace yaikchunk

@@ -18,6 +18,10 @@ int  writeGradientTile(FILE* f, int imgW, int imgH, int tileShiftX, int tileShif
 // 'PLNT' (:4516-4589)
 bool writePlaneTile(FILE* f, const BoundingBox& constraint, const u16* defs, size_t nDefs, const u8* idx, size_t idxBytes,
                     int planeType, bool halfX, bool halfY, std::string& err);
+// '3DTL' (EndCorrelationSearch, :7366-7678): the six tile maps (16x8, 8x16, 8x8, 8x4, 4x8, 4x4), tile types, box colours (CompressF'd here
+// with colorCompression), the 3/4/5/6-bit entry numbers (stored x 3).  The header keeps map sizes in 16 bits: larger maps are refused.
+struct Tile3DStreams { const u8* map[6]; size_t mapBytes[6]; const u16* tileType; size_t nTiles; const u8* color; const u8* idx[4]; size_t nIdx[4]; };
+bool writeTile3D(FILE* f, const Tile3DStreams& s, int colorCompression, int component, std::string& err);
 // '1DTL' (GenerateDynamicTileChunk, :8524-8576): type stream first, then the pixel stream
 bool writeTile1D(FILE* f, const u8* pix, size_t pixBytes, const u8* type, size_t typeBytes, int compressionColor,
                  int compressionRange, std::string& err);

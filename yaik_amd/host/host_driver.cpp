@@ -3,6 +3,8 @@
 // the MI355X drop-in.  tests/test_gpu_host_mirror.py checks its output blob by blob.
 //
 // usage: host_driver <in.bin> <out.blobs> [mode3BitOnly] [out.yaik]
+//        host_driver <in.bin> <out.blobs> lut <bank.bin>   3-D LUT tiles (Load3DPattern, Start/Correlation3DSearch x6/EndCorrelationSearch, :9117-9218)
+//                                                   behind the gradient passes, the '3DTL' chunk decoded back after YAIK_AssignLUT (see run_lut)
 //        host_driver <in.bin> <out.blobs> pp        the six plane-subset 4x4 passes of Convert() (:9261-9415) after the RGB passes, written
 //                                                   as a .yaik stream and decoded back (see run_partial below)
 // With the 4th argument the image is also converted to a .yaik stream (ConvertHotPath) and decoded back through the
@@ -11,6 +13,7 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <unistd.h>
 #include "EncoderContext.h"
 #include "yaik_decode.h"
 #include "chunks.h"
@@ -85,6 +88,85 @@ static int run_partial(EncoderContext* ctx, Image* img, int w, int h, int np) {
     return 0;
 }
 
+// The 3-D LUT part of Convert() against the mirror: bank files -> Load3DPattern, the six searches, '3DTL' chunk, LutFile -> YAIK_AssignLUT -> decode
+static int run_lut(EncoderContext* ctx, Image* img, int w, int h, int np, const char* bankPath) {
+    std::vector<u8> bank;
+    { FILE* fb = fopen(bankPath, "rb"); if (!fb) return 2; u8 tmp[4096]; size_t n; while ((n = fread(tmp, 1, sizeof tmp, fb)) > 0) bank.insert(bank.end(), tmp, tmp + n); fclose(fb); }
+    char dirT[] = "/tmp/yaikhostXXXXXX";
+    const char* dir = mkdtemp(dirT); if (!dir) return 2;
+    int nPat = 0;
+    for (size_t off = 0; off < bank.size(); nPat++) {
+        const size_t len = 1 + 3 * (size_t)bank[off];
+        const std::string name = std::string(dir) + "/pattern_" + std::to_string(nPat) + ".lut";
+        FILE* fp = fopen(name.c_str(), "wb"); if (!fp) return 2;
+        fwrite(&bank[off], 1, len, fp); fclose(fp);
+        ctx->Load3DPattern(name.c_str());
+        remove(name.c_str());
+        off += len;
+    }
+    if (ctx->correlationPatternCount3D != nPat) { fprintf(stderr, "%s\n", ctx->LastError()); return 4; }
+    FILE* yf = tmpfile(); if (!yf) return 2;
+    PaletteResetCodeBook();
+    if (!yaikchunk::writeFileHeader(yf, w, h, np == 4)) return 2;
+    ctx->outFile = yf;
+    if (np == 4) ctx->MipPrefilter(true);
+    static const int passes[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    for (int i = 0; i < 7; i++) ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), nullptr, false, passes[i][0], passes[i][1]);
+    ctx->StartCorrelationSearch(true);
+    static const int lp[6][2] = { {4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    int matched[6];
+    for (int i = 0; i < 6; i++) { ctx->Correlation3DSearch(img, nullptr, lp[i][0], lp[i][1]); matched[i] = ctx->LastCorrelationMatches(); }
+    blob("lut_matched", matched, sizeof matched);
+    ctx->EndCorrelationSearch(true, 7);
+    std::vector<u8> pix((size_t)w * h * 3 + 64);
+    u8* wr = pix.data();
+    for (int p = 0; p < 3; p++) wr = ctx->DynamicTileCompressor(wr, img->GetPlane(p), nullptr, nullptr);
+    blob("d1_pix", pix.data(), (size_t)(wr - pix.data()));
+    blob("d1_type", ctx->TileTypeStream1D().data(), ctx->TileTypeStream1D().size());
+    ctx->GenerateDynamicTileChunk(pix.data(), (int)(wr - pix.data()));
+    if (*ctx->LastError()) { fprintf(stderr, "%s\n", ctx->LastError()); return 4; }
+    if (!yaikchunk::writeEndOfFile(yf)) return 2;
+    ctx->outFile = nullptr;
+    fflush(yf);
+    const long n = ftell(yf);
+    std::vector<u32> stream(((size_t)n + 3) / 4);
+    fseek(yf, 0, SEEK_SET);
+    if (fread(stream.data(), 1, (size_t)n, yf) != (size_t)n) return 2;
+    fclose(yf);
+    blob("yaik_file", stream.data(), (size_t)n);
+    const std::string lutName = std::string(dir) + "/LutFile.lut";
+    if (!ctx->Save3DLutFile(lutName.c_str())) { fprintf(stderr, "%s\n", ctx->LastError()); return 4; }
+    std::vector<u8> lutFile;
+    { FILE* fl = fopen(lutName.c_str(), "rb"); if (!fl) return 2; u8 tmp[4096]; size_t k; while ((k = fread(tmp, 1, sizeof tmp, fl)) > 0) lutFile.insert(lutFile.end(), tmp, tmp + k); fclose(fl); remove(lutName.c_str()); }
+    rmdir(dir);
+    blob("lut_file", lutFile.data(), lutFile.size());
+    if ((w & 15) || (h & 15)) return 0;
+    YAIK_LIB lib = YAIK_Init(1, nullptr);
+    if (!lib) return 5;
+    static std::vector<u8> tiled;
+    YAIK_SDecodedImage di;
+    std::vector<u8> outImg((size_t)w * h * 4);
+    auto decodeOnce = [&]() -> int {
+        if (!YAIK_DecodeImagePre(lib, stream.data(), (u32)n, &di)) return (int)YAIK_GetErrorCode();
+        di.outputImage = outImg.data(); di.outputImageStride = di.width * 4;
+        di.customImageOutput = [](YAIK_SDecodedImage* u, YAIK_SCustomDataSource* s) {
+            const size_t planeSize = (size_t)(u->width / 8) * (u->height / 8) * 64;
+            tiled.assign(s->planeR, s->planeR + planeSize);
+            tiled.insert(tiled.end(), s->planeG, s->planeG + planeSize);
+            tiled.insert(tiled.end(), s->planeB, s->planeB + planeSize);
+        };
+        return YAIK_DecodeImage(stream.data(), (u32)n, &di) ? 0 : (int)YAIK_GetErrorCode();
+    };
+    int codes[2];
+    codes[0] = decodeOnce();                                          // no LUT assigned yet: the '3DTL' chunk must be refused (YAIK_INVALID_LUT)
+    YAIK_AssignLUT(lib, lutFile.data(), (u32)lutFile.size());
+    codes[1] = decodeOnce();
+    blob("yaik_lut_codes", codes, sizeof codes);
+    blob("yaik_planes_tiled", tiled.data(), tiled.size());
+    YAIK_Release(lib);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: host_driver in.bin out.blobs [mode3]\n"); return 2; }
     const bool mode3 = argc > 3 && atoi(argv[3]) != 0;
@@ -98,6 +180,12 @@ int main(int argc, char** argv) {
 
     EncoderContext* ctx = new EncoderContext();
     if (!ctx->SetImageToEncode(img)) { fprintf(stderr, "%s\n", ctx->LastError()); return 3; }
+    if (argc > 4 && std::string(argv[3]) == "lut") {
+        const int rc = run_lut(ctx, img, w, h, np, argv[4]);
+        fclose(gOut);
+        ctx->SetImageToEncode(nullptr); ctx->Release(); delete ctx;
+        return rc;
+    }
     if (argc > 3 && std::string(argv[3]) == "pp") {
         const int rc = run_partial(ctx, img, w, h, np);
         fclose(gOut);

@@ -28,6 +28,7 @@ struct Library {
     std::vector<Slot*> freeStack;
     std::mutex lock;                                    // the reference's stack is unguarded although Pre/Decode are documented thread-safe
     YAIK_SMemAlloc alloc;
+    bool hasLut = false;                                // YAIK_AssignLUT handed a valid 3-D LUT file to every decode slot
 };
 Library* gLib = nullptr;
 int gDevice = 0;
@@ -70,7 +71,17 @@ YAIK_LIB YAIK_Init(uint8_t maxDecodeThreadContext, YAIK_SMemAlloc* libraryMemAll
     return L;
 }
 
-void YAIK_AssignLUT(YAIK_LIB lib, uint8_t*, uint32_t) { if (!lib || lib != gLib) setError(YAIK_INVALID_LIBRARYCTX); }
+// decoder/YAIK_API.cpp:133-415: only the 3-D table file ('LUL') is accepted ('LU2' is deprecated there too); the per-orientation tables are
+// laid out in HBM by every decode slot's handle (yk_decode_assign_lut)
+void YAIK_AssignLUT(YAIK_LIB lib, uint8_t* lutData, uint32_t lutDataLength) {
+    if (!lib || lib != gLib) { setError(YAIK_INVALID_LIBRARYCTX); return; }
+    if (!lutData || lutDataLength < sizeof(LUTHeader) || lutData[0] != 'L' || lutData[1] != 'U' || lutData[2] != 'L') { setError(YAIK_INVALID_LUT); return; }
+    const uint32_t expected = ((uint32_t)lutData[5] + 1) * 3 * (64 + 32 + 16 + 8);
+    if (expected != lutDataLength - sizeof(LUTHeader)) { setError(YAIK_INVALID_LUT); return; }
+    for (auto& s : gLib->slots)
+        if (yk_decode_assign_lut(s.ctx, lutData, lutDataLength) != YK_OK) { setError(YAIK_MALLOC_FAIL); return; }
+    gLib->hasLut = true;
+}
 
 void YAIK_Release(YAIK_LIB lib) {
     if (!lib || lib != gLib) { setError(YAIK_RELEASE_EMPTY_LIBRARY); return; }
@@ -172,7 +183,34 @@ bool YAIK_DecodeImage(void* stream, uint32_t length, YAIK_SDecodedImage* info) {
                 break;
             }
             case 0x4d504c41u: setError(YAIK_ALPHA_UNSUPPORTED_YET); bad = true; break;                      // 'ALPM': alpha value coder, off the path
-            case 0x4c544433u: setError(YAIK_INVALID_LUT); bad = true; break;                                // '3DTL': needs the external LUT corpus, off the path
+            case TAG_TILE3D: {                                                                             // decoder/YAIK_API.cpp:999-1300
+                if (state > 4) break;
+                state = 4;
+                if (hb.length < sizeof(HeaderTile3D)) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
+                if (!gLib->hasLut) { setError(YAIK_INVALID_LUT); bad = true; break; }                       // the reference would read a NULL table here
+                HeaderTile3D th; memcpy(&th, body, sizeof th);
+                const uint8_t* q = body + sizeof th;
+                const uint32_t cmp[12] = { th.compr3BitSize, th.compr4BitSize, th.compr5BitSize, th.compr6BitSize, th.comprTypeSize, th.comprColorSize,
+                                           th.sizeT16_8MapCmp, th.sizeT8_16MapCmp, th.sizeT8_8MapCmp, th.sizeT8_4MapCmp, th.sizeT4_8MapCmp, th.sizeT4_4MapCmp };
+                const uint32_t raw[12] = { th.stream3BitCnt, th.stream4BitCnt, th.stream5BitCnt, th.stream6BitCnt, th.streamTypeCnt * 2, th.streamColorCnt,
+                                           th.sizeT16_8Map, th.sizeT8_16Map, th.sizeT8_8Map, th.sizeT8_4Map, th.sizeT4_8Map, th.sizeT4_4Map };
+                std::vector<uint8_t> part[12];
+                for (int k = 0; k < 12 && !bad; k++) {
+                    if (q + cmp[k] > endBlock) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
+                    if (raw[k] && !zexpand(q, cmp[k], raw[k], part[k], 256)) { bad = true; break; }
+                    q += cmp[k];
+                }
+                if (bad) break;
+                if (th.streamColorCnt != th.streamTypeCnt * 6) { setError(YAIK_INVALID_STREAM); bad = true; break; }      // the reference leaves this a TODO (:1079)
+                if (th.streamColorCnt) PaletteFullRangeRemapping(part[5].data(), (int)th.streamColorCnt, th.compressionRateColor);
+                const uint8_t* maps[6]; size_t mapBytes[6]; const uint8_t* idx[4]; size_t idxBytes[4]; size_t used[6];
+                for (int k = 0; k < 6; k++) { maps[k] = raw[6 + k] ? part[6 + k].data() : nullptr; mapBytes[k] = raw[6 + k]; }
+                for (int k = 0; k < 4; k++) { idx[k] = raw[k] ? part[k].data() : nullptr; idxBytes[k] = raw[k]; }
+                if (yk_decode_lut3d(s->ctx, maps, mapBytes, reinterpret_cast<const uint16_t*>(part[4].data()), th.streamTypeCnt, part[5].data(), idx, idxBytes, used) != YK_OK) {
+                    setError(YAIK_INVALID_STREAM); bad = true;
+                }
+                break;
+            }
             default: setError(YAIK_INVALID_TAG_ID); bad = true; break;
             }
             p = endBlock;

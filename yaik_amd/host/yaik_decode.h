@@ -3,10 +3,11 @@
 // reference's own YAIK.h and link this library instead of the reference decoder: the declarations below repeat that header's
 // types with identical layout, names and enumerator values so both sides agree on the ABI.
 //
-// On the path: file header, 'MIPM' (mask decode), 'GTIL' x7 (gradient decode), '1DTL' (range decode), terminator, the default
-// image builder (RGB888 / RGBA8888 rows at outputImageStride) and the custom-builder callback (8x8-tiled planes).
+// On the path: file header, 'MIPM' (mask decode), 'GTIL' (gradient decode, all planes or a plane subset), '3DTL' (3-D LUT tiles, after
+// YAIK_AssignLUT), '1DTL' (range decode), terminator, the default image builder (RGB888 / RGBA8888 rows at outputImageStride) and the
+// custom-builder callback (8x8-tiled planes).
 // Off the path (SURVEY §8 out of scope), reported through the sticky error code instead of decoded: 'ALPM' alpha value chunks
-// (YAIK_ALPHA_UNSUPPORTED_YET) and '3DTL' LUT tiles (YAIK_INVALID_LUT).  Images whose sides are not multiples of 16 are refused
+// (YAIK_ALPHA_UNSUPPORTED_YET); a '3DTL' chunk without an assigned LUT gives YAIK_INVALID_LUT.  Images whose sides are not multiples of 16 are refused
 // (YAIK_INVALID_HEADER): the reference's own loops mis-stride there (decoder/YAIK_Gradient.cpp:15).
 #pragma once
 #include <stddef.h>
@@ -53,7 +54,7 @@ enum YAIK_ERROR_CODE {
 };
 
 YAIK_LIB        YAIK_Init(uint8_t maxDecodeThreadContext, YAIK_SMemAlloc* libraryMemAllocator);
-void            YAIK_AssignLUT(YAIK_LIB lib, uint8_t* lutData, uint32_t lutDataLength);     // accepted and ignored: LUT tiles are off the path
+void            YAIK_AssignLUT(YAIK_LIB lib, uint8_t* lutData, uint32_t lutDataLength);     // the 3-D LUT file ('LUL0'); needed before a stream with a '3DTL' chunk
 void            YAIK_Release(YAIK_LIB lib);
 bool            YAIK_DecodeImagePre(YAIK_LIB lib, void* sourceStreamAligned, uint32_t streamLength, YAIK_SDecodedImage* getUserInfo);
 bool            YAIK_DecodeImage(void* sourceStreamAligned, uint32_t streamLength, YAIK_SDecodedImage* context);

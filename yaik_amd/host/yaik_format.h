@@ -1,5 +1,5 @@
 // On-disk layout of a .yaik stream, as the reference writes and reads it (include/YAIK_private.h:85-352 in KLab/YAIK).
-// Only the chunks of the tile hot path are described: 'MIPM', 'GTIL', 'PLNT', '1DTL'.  All structs are plain little-endian C
+// Only the chunks of the tile hot path are described: 'MIPM', 'GTIL', 'PLNT', '1DTL', '3DTL'.  All structs are plain little-endian C
 // layouts with the natural padding the reference's compilers give them; the static_asserts pin the sizes the reference's
 // decoder steps over with `&pHeader[1]`.  Padding bytes and `HeaderGradientTile::version` are never initialised by the
 // reference (they carry stack garbage there); this writer stores zeros.
@@ -13,6 +13,7 @@ static const u32 TAG_FILE     = 0x4b494159u;   // 'Y','A','I','K'  (encoder/Enco
 static const u32 TAG_MIPMAP   = 0x4d50494du;   // 'M','I','P','M'  (decoder/YAIK_API.cpp:560)
 static const u32 TAG_GRADTILE = 0x4c495447u;   // 'G','T','I','L'  (:562)
 static const u32 TAG_TILE1D   = 0x4c544431u;   // '1','D','T','L'  (:564)
+static const u32 TAG_TILE3D   = 0x4c544433u;   // '3','D','T','L'  (EndCorrelationSearch, EncoderContext.cpp:7589-7593; reader decoder/YAIK_API.cpp:999)
 static const u32 TAG_PLANE    = 0x544e4c50u;   // 'P','L','N','T'  (written by DynamicTileEncode, EncoderContext.cpp:4541-4545; no reader)
 static const u32 TAG_END      = 0xDEADBEEFu;   // terminator (EncoderContext.cpp:9779-9781)
 
@@ -42,6 +43,15 @@ struct Header1D {                               // :341-350
     u8 compressionColor, compressionRange, version;
 };
 
+struct HeaderTile3D {                           // :302-332
+    u32 streamColorCnt, streamTypeCnt, stream3BitCnt, stream4BitCnt, stream5BitCnt, stream6BitCnt;
+    u32 comprTypeSize, comprColorSize, compr3BitSize, compr4BitSize, compr5BitSize, compr6BitSize;
+    u16 sizeT16_8Map, sizeT8_16Map, sizeT8_8Map, sizeT4_8Map, sizeT8_4Map, sizeT4_4Map;
+    u16 sizeT16_8MapCmp, sizeT8_16MapCmp, sizeT8_8MapCmp, sizeT4_8MapCmp, sizeT8_4MapCmp, sizeT4_4MapCmp;
+    u8 component, compressionRateColor;
+};
+struct LUTHeader { u8 lutH[4]; u8 version, entryCount; u8 padding_extension[2]; };      // :75-80, the decoder's LUT file
+static_assert(sizeof(HeaderTile3D) == 76 && sizeof(LUTHeader) == 8, "3-D LUT chunk / file headers");
 static_assert(sizeof(FileHeader) == 12 && sizeof(HeaderBase) == 8, "file framing");
 static_assert(sizeof(MipmapHeader) == 16 && sizeof(HeaderGradientTile) == 28, "chunk headers");
 static_assert(sizeof(PlaneTile) == 24 && sizeof(Header1D) == 20, "chunk headers");
