@@ -9,7 +9,8 @@ out = {}
 
 def short(name):
     name = name.split("(")[0].strip()
-    return name.split(" ")[-1]
+    name = name.split(" ")[-1]
+    return name.split("<")[0]                      # template instantiations (yk_encode2_kernel<false>) under the kernel's name
 
 for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
