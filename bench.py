@@ -83,12 +83,25 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         if world > 1:
             dist.barrier()
 
-    ST = {"corners": (0,), "range1d": (1, 2), "decode": (3, 4, 5)}[args.stage]
+    ST = {"corners": (0,), "range1d": (1, 2), "decode": (3, 4, 5), "lut3d": (6,)}[args.stage]
     dec = None
     if args.stage == "corners":
         step = enc.gradient_corners_run
     elif args.stage == "range1d":
         step = lambda: lib_call(enc)
+    elif args.stage == "lut3d":
+        # SURVEY 8(f)4 on the synthetic bank (the reference's own is not in its repository): the six search passes of Convert() on what the
+        # gradient passes of the bench frame left uncovered.  Every step re-encodes first (untimed part of the step would distort: the
+        # encode is 0.4 ms against tens of ms of search), because a search pass consumes the coverage it paints.
+        from yaik_amd.synth import bank_patterns
+        for pat in bank_patterns():
+            enc.lut_load(pat)
+        lut_matched = [0]
+
+        def step():
+            enc.encode(3, args.mode3, False)
+            enc.lut_start()
+            lut_matched[0] = sum(enc.lut_search(sx, sy) for sx, sy in ((4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)))
     else:
         # streams for the decoder come from the GPU encoder: tile bitmaps, corner streams (de-quantised like PaletteFullRangeRemapping,
         # decoder/YAIK_GenericFunctions.cpp:128-137: v * ((255 << 16) / 250) >> 16) and the 1-D streams
@@ -140,6 +153,12 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         pixn = uncovered * 3
         alg = 12 * W * W + pixn + 64 * 0 + (W // 8) * (W // 8) * 3 * 3     # three int32 planes read once + 1 B per uncovered pixel and plane + 3 parameter bytes per tile-plane
         kname, kms, note = "yk_range1d_kernel", per[1], f"scan + pack kernels: {per[2]:.4f} ms per frame on top"
+    elif args.stage == "lut3d":
+        cand = int((~cov).sum()) * 16                         # pixels of tiles with anything left to code, an upper bound of what the passes read
+        alg = 12 * cand * 6                                   # every pass reads the three int32 samples of its candidate tiles' pixels once
+        kname, kms = "yk_lut_search_kernel (6 tile shapes)", per[6]
+        note = (f"gather-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations distance-field look-ups per candidate tile; "
+                f"{lut_matched[0]} tiles matched on this frame; algorithmic bytes = the candidate tiles' samples once per pass")
     else:
         pixn = uncovered * 3
         alg = pixn + 3 * W * W                              # yk_dec1d_kernel: 1 B per uncovered pixel and plane read + the pixels it writes (<= 3 B/pixel); the dominant decode kernel by bytes
@@ -305,9 +324,10 @@ def main() -> int:
                     "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
                     "frames, where the ~8 stream operations per frame are what limits the rate; per-kernel times are then one interval")
-    ap.add_argument("--stage", choices=["encode", "corners", "range1d", "decode"], default="encode", help="which stage of the path a step runs: encode = the "
+    ap.add_argument("--stage", choices=["encode", "corners", "range1d", "decode", "lut3d"], default="encode", help="which stage of the path a step runs: encode = the "
                     "headline (alpha reject + fused gradient/range kernel + compaction); corners = the seven corner-colour streams (a6 rgbStream); "
-                    "range1d = the live 1-D range path (a15); decode = gradient + 1-D decode + de-tile on the GPU (a16, a17, a20)")
+                    "range1d = the live 1-D range path (a15); decode = gradient + 1-D decode + de-tile on the GPU (a16, a17, a20); lut3d = the 3-D LUT tile search "
+                    "(f4) on a synthetic bank, after an encode")
     ap.add_argument("--layout", choices=["frames", "stripes"], default="frames", help="N > 1: frames = every rank encodes its own frames (weak scaling, "
                     "default); stripes = ONE image of --size, rank r owns a band of 64-row blocks + 1 halo row (strong scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -156,6 +156,11 @@ int    yk_gradient_corner_edges(yk_ctx* c, uint32_t* hostKeys, uint32_t* hostInd
  * The 2-D tile maps of yk_encode_tiles are not touched (the reference's partial passes precede only the 1-D compressor).
  * Single images only (nFrames == 1, whole image: y0 == 0).  *tilesAccepted = the function's return value (TileDone).  Synchronises. */
 int    yk_gradient_partial_pass(yk_ctx* c, int rejectFactor, int planeBit, int tileShiftX, int tileShiftY, int* tilesAccepted);
+/* testOutput of FittingQuadSmooth (:3960-3971, :4096-4104): the tiles pass `pass` accepted (0..6 = the RGB passes, 7 = the last plane-subset
+ * pass) write blendC6Exp - the rounded bilinear blend of their Round6P corners - into three int32 preview planes the handle keeps per
+ * encode (INT32_MIN where no tile wrote yet).  Calls accumulate; hostOut (may be NULL) receives the three planes, w*h each.  A debugging
+ * aid of the encoder, not what the decoder reconstructs.  Single whole images. */
+int    yk_gradient_preview(yk_ctx* c, int pass, int32_t* hostOut, size_t capElems);
 /* bitmap (swizzled like yk_gradient_bitmap, size :3770-3777) and corner stream of the LAST partial pass */
 int    yk_partial_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
 int    yk_partial_corners(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes);
@@ -302,7 +307,8 @@ enum { YK_STAGE_CORNERS = 0,       /* yk_gradient_corners: lattice clear + owner
        YK_STAGE_RANGE1D_PACK = 2,  /* yk_range1d_encode: scans + yk_range1d_pack_kernel */
        YK_STAGE_DEC_GRADIENT = 3,  /* yk_decode_gradient: owner / corner / scan / render kernels of one pass per interval */
        YK_STAGE_DEC_1D = 4,        /* yk_decode_1d: count / scans / yk_dec1d_kernel */
-       YK_STAGE_DEC_DETILE = 5 };  /* yk_decode_output: yk_dec_detile_kernel */
+       YK_STAGE_DEC_DETILE = 5,    /* yk_decode_output: yk_dec_detile_kernel */
+       YK_STAGE_LUT3D = 6 };       /* yk_lut_search: yk_lut_search_kernel (one interval per tile shape) */
 int yk_stage_ms(yk_ctx* c, int stage, float* msSum, int* intervals);
 
 #ifdef __cplusplus

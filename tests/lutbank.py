@@ -6,27 +6,7 @@ hands Set3DPointCloud the original count (:7907-7917), which reads and writes pa
 import numpy as np
 
 
-def bank_patterns(n_patterns: int = 6) -> list:
-    """List of uint8 arrays [count, 3] (r, g, b in 0..63)."""
-    i = np.arange(64, dtype=np.float64)
-    t = i / 63.0
-    pats = [
-        np.stack([i, i, i], 1),                                                    # the diagonal: colours between two end points
-        np.stack([i, 63 * t * t, i], 1),                                           # one channel lags
-        np.stack([i, 63 * np.sqrt(t), 63 * t * t], 1),                             # one leads, one lags
-        np.stack([i, np.minimum(2 * i, 63), np.maximum(2 * i - 63, 0)], 1),        # a bent path through a cube edge
-        np.stack([63 * (1 - np.cos(np.pi * t)) / 2, i, 63 - i], 1),                # S-curve against a falling channel
-        np.stack([i[:40] * 63 / 39, 63 - i[:40] * 63 / 39, i[:40] * 63 / 39 * 0.5], 1),   # 40 points only
-    ]
-    return [np.clip(np.floor(p + 0.5), 0, 63).astype(np.uint8) for p in pats[:n_patterns]]
-
-
-def bank_bytes(patterns) -> bytes:
-    out = bytearray()
-    for p in patterns:
-        out.append(len(p))
-        out += p[:, 0].tobytes() + p[:, 1].tobytes() + p[:, 2].tobytes()
-    return bytes(out)
+from yaik_amd.synth import bank_bytes, bank_patterns  # noqa: E402,F401  (the generator lives with the other synthetic inputs)
 
 
 def lut_image(w: int, h: int, patterns=None, seed: int = 3) -> np.ndarray:

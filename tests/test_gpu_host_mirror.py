@@ -47,7 +47,7 @@ def test_cpp_operator_surface_matches_oracle(oracle_built, case, mode3):
         if got[f"grad_rgbraw_{i}"] != rgb.tobytes():
             bad.append(f"rgb{i}")
     m = 1 if mode3 else 0
-    names = ["grad_counts", "d1_pix", "d1_type"] + [f"plnt_{k}_{m}_{p}" for k in ("defs", "idx", "dst") for p in range(3)]
+    names = ["grad_counts", "d1_pix", "d1_type"] + [f"plnt_{k}_{m}_{p}" for k in ("defs", "idx", "dst") for p in range(3)] + [f"preview_{p}" for p in range(3)]
     if planes.shape[0] == 4:
         names += ["mip_bounds", "_mip_bitmap"]
     for k in names:

@@ -78,6 +78,26 @@ def test_partial_passes_match_oracle(hip, oracle_built, name):
     assert np.array_equal(gtyp, typ) and np.array_equal(gpix, pix)
 
 
+@pytest.mark.parametrize("kind,w,h", [("planemix", 128, 128), ("mixed", 200, 136), ("photo", 256, 256)])
+def test_preview_planes_match_oracle(hip, oracle_built, kind, w, h):
+    """FittingQuadSmooth's testOutput planes (blendC6Exp of the accepted tiles), RGB passes and a plane-subset pass."""
+    planes = edge_image(w, h, kind, 3)
+    ora = OracleEncoder(planes)
+    hip.set_image(planes)
+    hip.encode(3, False, False)
+    for sx, sy in PASSES:
+        ora.fitting_quad_smooth(sx, sy)
+    got = hip.gradient_preview(range(7))
+    want = np.stack([ora.state("preview", p) for p in range(3)])
+    assert np.array_equal(np.where(got == np.iinfo(np.int32).min, 0, got), want)
+    assert (got != np.iinfo(np.int32).min).any()
+    ora.fitting_quad_smooth(2, 2, plane_bit=5)
+    hip.fitting_quad_smooth_planes(5)
+    got = hip.gradient_preview([7])
+    want = np.stack([ora.state("preview", p) for p in range(3)])
+    assert np.array_equal(np.where(got == np.iinfo(np.int32).min, 0, got), want)
+
+
 def test_partial_passes_other_shapes_and_state(hip, oracle_built):
     """Any tile shape the function takes, masks in another order, and the state rules: a new encode forgets the partial passes."""
     planes = edge_image(192, 128, "planemix", 3, seed=9)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "yk_coverage": (C.c_int, [vp, vp, sz]),
     "yk_gradient_corners": (C.c_int, [vp, C.c_int, vp, sz, szp]),
     "yk_gradient_partial_pass": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "yk_gradient_preview": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_partial_bitmap": (C.c_int, [vp, vp, sz, szp]),
     "yk_partial_corners": (C.c_int, [vp, vp, sz, szp]),
     "yk_coverage_plane": (C.c_int, [vp, C.c_int, vp, sz]),

@@ -37,10 +37,10 @@ static void yk_free_image(yk_ctx* c) {
     c->coverage = nullptr; c->tileDef = nullptr; c->tileCount = nullptr; c->slots = nullptr;
     c->blockSums = nullptr; c->blockCnt = nullptr; c->totals = nullptr; c->defsOut = nullptr; c->nibOut = nullptr;
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
-    F(c->covCh); F(c->mapped3); F(c->ppBitmap); F(c->ppStream); F(c->ppScratch); c->ppBitmapBytes = c->ppBitmapCap = 0; c->ppStreamCap = c->ppStreamBytes = 0; c->ppScratchElems = 0;
+    F(c->preview); F(c->covCh); F(c->mapped3); F(c->ppBitmap); F(c->ppStream); F(c->ppScratch); c->ppBitmapBytes = c->ppBitmapCap = 0; c->ppStreamCap = c->ppStreamBytes = 0; c->ppScratchElems = 0;
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
     if (c->frameGraph) { (void)hipGraphExecDestroy(c->frameGraph); c->frameGraph = nullptr; }
-    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
 }
 
 // allocates every per-image array c->nFrames times (geometry fields are set) and points the handle at frame 0
@@ -192,7 +192,7 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
     YK_HIP(c, hipSetDevice(c->device));
     c->fusedAfter = nullptr;                                                 // an ordering request never outlives the image it was made for
     if (c->fullW == fullW && c->fullH == fullH && c->nPlanes == nPlanes && c->y0 == y0 && c->h == h && c->halo == haloRows && c->tileCount) {
-        c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false;
+        c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
         return YK_OK;
     }
     YK_HIP(c, hipStreamSynchronize(c->stream));
@@ -229,7 +229,7 @@ int yk_select_frame(yk_ctx* c, int frame) {
     if (!c->tileCount) return yk_fail(c, YK_ERR_STATE, "yk_set_image first");
     if (frame < 0 || frame >= c->nFrames) return yk_fail(c, YK_ERR_BAD_ARG, "frame out of range");
     yk_rebase(c, frame);
-    c->cornersReady = false; c->ppActive = false; c->r1Ready = false;
+    c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false; c->r1Ready = false;
     return YK_OK;
 }
 
@@ -259,7 +259,7 @@ int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideEl
     }
     c->fs.plane = 0; yk_rebase(c, 0);
     c->strideElems = c->fullW;
-    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
     return YK_OK;
 }
 
@@ -273,7 +273,7 @@ int yk_bind_device_planes(yk_ctx* c, const int32_t* const devPlanes[4], int stri
     }
     c->fs.plane = 0; yk_rebase(c, 0);
     c->strideElems = strideElems;
-    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
     return YK_OK;
 }
 
@@ -287,7 +287,7 @@ int yk_bind_device_batch(yk_ctx* c, const int32_t* const frame0Planes[4], int st
     }
     c->fs.plane = frameStrideElems; yk_rebase(c, c->curFrame < c->nFrames ? c->curFrame : 0);
     c->strideElems = strideElems;
-    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false;
+    c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
     return YK_OK;
 }
 
@@ -416,7 +416,7 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
     c->evAlphaInCur = false;
     c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;       // the oldest sets were overwritten
-    c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->ppActive = false; c->nextCornerPass = 0; c->r1Ready = false;
+    c->encoded = true; c->dstValid = wantDst != 0; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 
@@ -450,7 +450,7 @@ int yk_encode_batch(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
     c->evAlphaInCur = false; c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;
     c->alphaDone = c->nPlanes == 4; c->alphaFinished = true;
-    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->ppActive = false; c->nextCornerPass = 0; c->r1Ready = false;
+    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 
@@ -488,7 +488,7 @@ int yk_encode_frame(yk_ctx* c, int rejectFactor, int mode3BitOnly) {
     c->evAlphaInCur = false; c->evHead++;
     if (c->evHead - c->evTail > YK_EV_RING) c->evTail = c->evHead - YK_EV_RING;
     c->alphaDone = c->nPlanes == 4; c->alphaFinished = true;
-    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->ppActive = false; c->nextCornerPass = 0; c->r1Ready = false;
+    c->encoded = true; c->dstValid = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false; c->nextCornerPass = 0; c->r1Ready = false;
     return YK_OK;
 }
 

@@ -11,7 +11,7 @@
 #define YK_LROWS    65
 #define YK_EV_RING  64
 #define YK_SLOT     32      // bytes of nibble slot per 8x8 tile-plane (64 nibbles)
-#define YK_NUM_STAGES 6     // YK_STAGE_* of include/yaik_hip.h
+#define YK_NUM_STAGES 7     // YK_STAGE_* of include/yaik_hip.h
 #define YK_STAGE_RING 16
 
 // Batches: one handle can hold nFrames images of one shape; every per-image array is allocated nFrames times back to back and
@@ -103,6 +103,8 @@ struct yk_ctx {
     uint8_t* mapped3 = nullptr;                            // bit p = plane p's corner at this lattice point has been emitted
     uint32_t* ppBitmap = nullptr; size_t ppBitmapBytes = 0; uint8_t* ppStream = nullptr; size_t ppStreamCap = 0, ppStreamBytes = 0;
     uint32_t* ppScratch = nullptr; size_t ppScratchElems = 0, ppBitmapCap = 0; int ppAccepted = 0; bool ppActive = false;
+    int ppLastBit = 0, ppLastSx = 0, ppLastSy = 0;         // the last plane-subset pass (its bitmap is ppBitmap)
+    int32_t* preview = nullptr; bool previewFresh = false; // FittingQuadSmooth's testOutput planes (3 x w*h int32), INT32_MIN where no tile wrote
     // (f)4 3-D LUT tiles (yk_lut3d.hip): pattern bank + the streams StartCorrelationSearch allocates
     struct YkLutState* lut = nullptr;
     struct YkLutDecState* lutDec = nullptr;      // decoder: the per-orientation tables YAIK_AssignLUT lays out

@@ -426,8 +426,10 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     YK_HIP(c, hipMalloc(&slots, nSlots * sizeof(LutSlot)));
     YK_HIP(c, hipMalloc(&slotIdx, nSlots * nPix));
     YK_HIP(c, hipMalloc(&sums, (5 * nb + 16) * sizeof(uint32_t)));
+    { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(128), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
                        S->bankDev, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
+    { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_lut_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, slots, nSlots, sums, nb);
     hipLaunchKernelGGL(yk_lut_scan_kernel, dim3(1), dim3(1024), 0, c->stream, sums, nb, sums + 5 * nb);
     LutStreams out; out.tileType = S->tileType; out.color = S->color; out.nType = S->nType; out.nColor = S->nColor;

@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void yk_pp_mark_kernel(const uint32_t* __restr
     if (i < lat && owner[i] != 0xFFFFFFFFu) mapped3[i] |= (uint8_t)planeBit;
 }
 
+// testOutput of FittingQuadSmooth (:3960-3971, :4096-4104): every accepted tile writes blendC6Exp, the rounded bilinear blend of the
+// Round6P corners, into the preview planes of its present planes -- an encoder-side debugging aid (the decoder reconstructs from the
+// Round6 corners de-quantised through CompressF, not this).  One thread per tile slot; not on any timed path.
+__global__ __launch_bounds__(256) void yk_pp_preview_kernel(PPPlanes P, PPGeo g, size_t nBits, int planeBit, const uint32_t* __restrict__ bitmap, int32_t* __restrict__ preview, size_t planeElems) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nBits || !((bitmap[pos >> 5] >> (pos & 31)) & 1u)) return;
+    int x, y; yk_pp_tile(g, (uint32_t)pos, x, y);
+    const int TX = 1 << g.sx, TY = 1 << g.sy;
+    if (x + TX > P.w || y + TY > P.h) return;
+    for (int n = 0; n < 3; n++) {
+        if (!((planeBit >> n) & 1)) continue;
+        const int c0 = yk_pp_r6p(yk_pp_px(P, n, x, y)), c1 = yk_pp_r6p(yk_pp_px(P, n, x + TX, y)), c2 = yk_pp_r6p(yk_pp_px(P, n, x, y + TY)), c3 = yk_pp_r6p(yk_pp_px(P, n, x + TX, y + TY));
+        for (int dy = 0; dy < TY; dy++) {
+            const int tF = 1024 - dy * (1024 >> g.sy), bF = 1024 - tF;
+            for (int dx = 0; dx < TX; dx++) {
+                const int lF = 1024 - dx * (1024 >> g.sx), rF = 1024 - lF;
+                preview[(size_t)n * planeElems + (size_t)(y + dy) * P.w + (x + dx)] = ((c0 * lF + c1 * rF) * tF + (c2 * lF + c3 * rF) * bF + ((1 << 19) - 1)) >> 20;
+            }
+        }
+    }
+}
+__global__ void yk_pp_fill_i32_kernel(int32_t* __restrict__ p, size_t n, int32_t v) { const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
 // Per-plane state of the passes that follow the seven RGB passes (plane-subset gradient passes, 3-D LUT tiles): every plane starts from
 // the common coverage, every lattice point an RGB pass emitted is known to all planes.  Idempotent until the next encode.
 int yk_pp_activate(yk_ctx* c) {
@@ -208,10 +231,42 @@ int yk_gradient_partial_pass(yk_ctx* c, int rejectFactor, int planeBit, int sx, 
     YK_HIP(c, hipMemcpyAsync(res, total, sizeof res, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
     c->ppStreamBytes = res[0]; c->ppAccepted = (int)res[1];
+    c->ppLastBit = planeBit; c->ppLastSx = sx; c->ppLastSy = sy;
     c->r1Ready = false;                                                      // the 1-D path now has less to code
     if (tilesAccepted) *tilesAccepted = c->ppAccepted;
     // the byte size of this pass's bitmap as the reference allocates it (:3770-3777)
     c->ppBitmapBytes = (size_t)(nBits >> 3);
+    return YK_OK;
+}
+
+int yk_gradient_preview(yk_ctx* c, int pass, int32_t* hostOut, size_t capElems) {
+    if (!c || pass < 0 || pass > 7) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    if (c->nFrames != 1 || c->y0 != 0 || c->h != c->fullH) return yk_fail(c, YK_ERR_STATE, "the preview planes exist for single whole images");
+    if (pass == 7 && (!c->ppActive || !c->ppBitmap || c->ppLastBit == 0)) return yk_fail(c, YK_ERR_STATE, "no plane-subset pass ran since the encode");
+    YK_HIP(c, hipSetDevice(c->device));
+    const int w = c->fullW, h = c->h;
+    const size_t planeElems = (size_t)w * h;
+    if (!c->preview) { YK_HIP(c, hipMalloc(&c->preview, 3 * planeElems * sizeof(int32_t))); c->previewFresh = false; }
+    if (!c->previewFresh) {                                                  // a new encode starts from untouched planes (INT32_MIN = no tile wrote here)
+        hipLaunchKernelGGL(yk_pp_fill_i32_kernel, dim3((unsigned)((3 * planeElems + 255) / 256)), dim3(256), 0, c->stream, c->preview, 3 * planeElems, (int32_t)0x80000000);
+        c->previewFresh = true;
+    }
+    static const int shp[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    const int sx = pass < 7 ? shp[pass][0] : c->ppLastSx, sy = pass < 7 ? shp[pass][1] : c->ppLastSy, planeBit = pass < 7 ? 7 : c->ppLastBit;
+    const PPGeo g = yk_pp_geo(sx, sy, w);
+    const size_t nBits = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount;
+    PPPlanes P; for (int n = 0; n < 3; n++) P.p[n] = c->plane[n];
+    P.strideElems = c->strideElems; P.w = w; P.h = h; P.hAvail = h + c->halo;
+    const uint32_t* bm = pass < 7 ? reinterpret_cast<const uint32_t*>(c->bitmap[pass]) : c->ppBitmap;
+    if (pass < 7 && (c->bitmapBytes[pass] & 3)) YK_HIP(c, hipMemsetAsync(c->bitmap[pass] + c->bitmapBytes[pass], 0, 4 - (c->bitmapBytes[pass] & 3), c->stream));
+    hipLaunchKernelGGL(yk_pp_preview_kernel, dim3((unsigned)((nBits + 255) / 256)), dim3(256), 0, c->stream, P, g, nBits, planeBit, bm, c->preview, planeElems);
+    YK_HIP(c, hipGetLastError());
+    if (hostOut) {
+        if (capElems < 3 * planeElems) return yk_fail(c, YK_ERR_RANGE, "preview buffer too small (3 planes of w*h int32)");
+        YK_HIP(c, hipMemcpyAsync(hostOut, c->preview, 3 * planeElems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
 }
 

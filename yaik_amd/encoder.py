@@ -192,6 +192,13 @@ class HipTileEncoder:
             _chk(self._h, L.yk_partial_corners(self._h, cs.ctypes.data, cs.size, None))
         return int(n.value), bm, cs
 
+    def gradient_preview(self, passes=range(7)) -> np.ndarray:
+        """FittingQuadSmooth's testOutput planes [3, h, w] int32 after the given passes (7 = the last plane-subset pass); INT32_MIN = untouched."""
+        out = np.zeros((3, self.h, self.w), dtype=np.int32)
+        for p in passes:
+            _chk(self._h, lib().yk_gradient_preview(self._h, int(p), out.ctypes.data, out.size))
+        return out
+
     def coverage_plane(self, plane: int) -> np.ndarray:
         """[h/4, w/4] bool: 4x4 cell of `plane` covered by an accepted tile (mapSmoothTile[plane] != 0)."""
         mtw, mth = (self.w + 15) // 16, (self.h + 15) // 16

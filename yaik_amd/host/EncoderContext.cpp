@@ -93,7 +93,20 @@ bool EncoderContext::ensureEncoded(int rejectFactor, bool mode3, bool wantDst) {
     return true;
 }
 
-int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* /*testOutput*/, bool useYCoCg,
+// testOutput (:4096-4104): the pass's accepted tiles write their blendC6Exp preview into the planes that took part
+static bool copyPreview(yk_ctx* ctx, int pass, int planeBit, Image* testOutput, int w, int h) {
+    std::vector<int32_t> buf((size_t)3 * w * h);
+    if (yk_gradient_preview(ctx, pass, buf.data(), buf.size()) != YK_OK) return false;
+    for (int n = 0; n < 3; n++) {
+        if (!((planeBit >> n) & 1) || !testOutput->GetPlane(n)) continue;
+        int* d = testOutput->GetPlane(n)->GetPixels();
+        const int32_t* src = buf.data() + (size_t)n * w * h;
+        for (size_t i = 0; i < (size_t)w * h; i++) if (src[i] != INT_MIN) d[i] = src[i];
+    }
+    return true;
+}
+
+int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* testOutput, bool useYCoCg,
                                       int tileBitSizeX, int tileBitSizeY) {
     if (!bound) { fail("FittingQuadSmooth: SetImageToEncode first"); return 0; }
     if (useYCoCg) { fail("FittingQuadSmooth: the YCoCg variant is not on this path"); return 0; }
@@ -120,6 +133,7 @@ int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plan
                                              gradBitmap.size(), gradRgb.data(), gradRgb.size(), colorCompressionQuad, planeBit, e) < 0) { fail(("FittingQuadSmooth: " + e).c_str()); return 0; }
             fileOutSize += (int)(ftell(outFile) - before);
         }
+        if (testOutput && !copyPreview(ctx, 7, planeBit, testOutput, original->GetWidth(), original->GetHeight())) { fail("yk_gradient_preview"); return 0; }
         return tiles;
     }
     int pass = -1;
@@ -142,6 +156,7 @@ int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plan
                                          gradBitmap.size(), gradRgb.data(), gradRgb.size(), colorCompressionQuad, 7, e) < 0) { fail(("FittingQuadSmooth: " + e).c_str()); return 0; }
         fileOutSize += (int)(ftell(outFile) - before);
     }
+    if (testOutput && !copyPreview(ctx, pass, 7, testOutput, original->GetWidth(), original->GetHeight())) { fail("yk_gradient_preview"); return 0; }
     int tiles = 0;
     for (u8 v : gradBitmap) tiles += __builtin_popcount(v);               // TileDone (:4362)
     return tiles;

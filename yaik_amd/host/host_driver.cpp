@@ -210,6 +210,11 @@ int main(int argc, char** argv) {
         blob(nm("grad_rgbraw", i), ctx->LastGradientRGBStream().data(), ctx->LastGradientRGBStream().size());
     }
     blob("grad_counts", counts, sizeof counts);
+    for (int p = 0; p < 3; p++) {                                  // testOutput as FittingQuadSmooth left it
+        std::vector<short> p16((size_t)w * h);
+        for (size_t i = 0; i < p16.size(); i++) p16[i] = (short)preview->GetPlane(p)->GetPixels()[i];
+        blob(nm("preview", p), p16.data(), p16.size() * 2);
+    }
     for (int p = 0; p < 3; p++) {
         Plane* dst = new Plane(w, h);
         BoundingBox full = dst->GetRect(); dst->Fill(full, -1);

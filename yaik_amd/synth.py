@@ -106,3 +106,29 @@ def synth_planes_torch(w: int, h: int | None = None, n_planes: int = 4, seed: in
         holes = (((x >> 7) + (y >> 7)) % 5) == 0
         out[3] = torch.where(frame | holes, 0, 255).to(torch.int32)
     return out
+
+
+# ---- synthetic 3-D LUT bank: the reference's own bank (22 'Bank3D//*.lut' files) is not in its repository -------------------
+def bank_patterns(n_patterns: int = 6) -> list:
+    """Point-cloud patterns in the 64^3 cube (uint8 [count, 3], 6-bit r, g, b): the content of `Load3DPattern` files (EncoderContext.cpp:7851)."""
+    i = np.arange(64, dtype=np.float64)
+    t = i / 63.0
+    pats = [
+        np.stack([i, i, i], 1),                                                    # the diagonal: colours between two end points
+        np.stack([i, 63 * t * t, i], 1),                                           # one channel lags
+        np.stack([i, 63 * np.sqrt(t), 63 * t * t], 1),                             # one leads, one lags
+        np.stack([i, np.minimum(2 * i, 63), np.maximum(2 * i - 63, 0)], 1),        # a bent path through a cube edge
+        np.stack([63 * (1 - np.cos(np.pi * t)) / 2, i, 63 - i], 1),                # S-curve against a falling channel
+        np.stack([i[:40] * 63 / 39, 63 - i[:40] * 63 / 39, i[:40] * 63 / 39 * 0.5], 1),   # 40 points only
+    ]
+    return [np.clip(np.floor(p + 0.5), 0, 63).astype(np.uint8) for p in pats[:n_patterns]]
+
+
+def bank_bytes(patterns) -> bytes:
+    out = bytearray()
+    for p in patterns:
+        out.append(len(p))
+        out += p[:, 0].tobytes() + p[:, 1].tobytes() + p[:, 2].tobytes()
+    return bytes(out)
+
+
