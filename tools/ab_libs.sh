@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of library builds: tools/r02_ab.sh <tag> libA libB ...   (per-class fused-kernel times, the bench frame, the bench line)
+# same-box A/B of library builds: tools/ab_libs.sh <tag> libA libB ...   (per-class fused-kernel times, the bench frame, the bench line)
 TAG=$1; shift
 mkdir -p gpurun_out/r02
 O=gpurun_out/r02/ab_$TAG.log

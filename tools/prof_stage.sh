@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one stage bench: tools/r02_prof_stage.sh <stage>
+# rocprofv3 kernel stats of one stage bench: tools/prof_stage.sh <stage>
 ST=$1
 mkdir -p gpurun_out/r02
 cd /tmp && export TMPDIR=/tmp
