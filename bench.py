@@ -312,8 +312,8 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--mode3", action="store_true", help="3-bpp range modes only (DynamicTileEncode mode3BitOnly)")
     ap.add_argument("--in-flight", type=int, default=2, help="frames per GPU kept in flight on separate handles/streams (a step = that many frames per "

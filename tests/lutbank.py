@@ -45,3 +45,22 @@ def lut_image(w: int, h: int, patterns=None, seed: int = 3) -> np.ndarray:
                         v = 1.0 - v
                     out[c][sl[1:]] = np.floor(c0[c] + v * (c1[c] - c0[c]) + 0.5)
     return np.ascontiguousarray(np.clip(out, 0, 255).astype(np.int32))
+
+
+def random_bank(seed: int, n_patterns: int = 5) -> list:
+    """Banks no curve designer would draw: random point counts (1..64), unordered points, duplicates, clusters -- the tables and the search
+    must agree with the reference on them too."""
+    rng = np.random.default_rng(seed)
+    pats = []
+    for k in range(n_patterns):
+        n = int(rng.integers(1, 65))
+        if k % 3 == 0:
+            p = rng.integers(0, 64, (n, 3))
+        elif k % 3 == 1:
+            t = np.sort(rng.random(n))
+            p = np.stack([63 * t, 63 * t ** float(rng.uniform(0.4, 2.5)), 63 * (1 - t) ** float(rng.uniform(0.4, 2.5))], 1) + rng.integers(-2, 3, (n, 3))
+        else:
+            c = rng.integers(8, 56, (4, 3))
+            p = c[rng.integers(0, 4, n)] + rng.integers(-6, 7, (n, 3))
+        pats.append(np.clip(np.floor(p + 0.5), 0, 63).astype(np.uint8))
+    return pats

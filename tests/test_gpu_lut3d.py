@@ -8,7 +8,7 @@ import pytest
 from oracle.pyoracle import PASSES, OracleEncoder
 from tests.blobs import LUT_PASSES
 from tests.golden.make_golden import LUT3D
-from tests.lutbank import bank_patterns, lut_image
+from tests.lutbank import bank_patterns, lut_image, random_bank
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -51,6 +51,9 @@ def test_pattern_tables_match_oracle(hip, oracle_built):
 
 
 CASES = {
+    "random_bank_a": lambda: (lut_image(128, 128, random_bank(101), seed=41), random_bank(101)),
+    "random_bank_b": lambda: (lut_image(144, 112, random_bank(102, 7), seed=42), random_bank(102, 7)),
+    "random_bank_c": lambda: (lut_image(256, 256, random_bank(104, 9), seed=43), random_bank(104, 9)),
     "lut128": lambda: (lut_image(128, 128, seed=11), bank_patterns()),
     "lut200x136": lambda: (lut_image(200, 136, seed=5), bank_patterns()),
     "lut256_3patterns": lambda: (lut_image(256, 256, bank_patterns(3), seed=2), bank_patterns(3)),

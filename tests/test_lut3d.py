@@ -9,7 +9,7 @@ import pytest
 from oracle.refrun import have_ref, run_reference
 from tests.blobs import compare_lut, oracle_lut_blobs
 from tests.golden.make_golden import LUT3D
-from tests.lutbank import bank_bytes, bank_patterns, lut_image
+from tests.lutbank import bank_bytes, bank_patterns, lut_image, random_bank
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -27,6 +27,9 @@ LIVE = {
     "lut128": lambda: (lut_image(128, 128, seed=11), bank_patterns()),
     "lut200x136": lambda: (lut_image(200, 136, seed=5), bank_patterns()),          # partial tiles on both edges
     "lut256_3patterns": lambda: (lut_image(256, 256, bank_patterns(3), seed=2), bank_patterns(3)),
+    "random_bank_a": lambda: (lut_image(128, 128, random_bank(101), seed=41), random_bank(101)),
+    "random_bank_b": lambda: (lut_image(144, 112, random_bank(102, 7), seed=42), random_bank(102, 7)),
+    "random_bank_on_photo": lambda: (__import__("tests.images", fromlist=["edge_image"]).edge_image(128, 128, "photo", 3), random_bank(103, 4)),
 }
 
 
