@@ -62,7 +62,11 @@ def select_kernel_version(enc, version: int) -> None:
     import os
     from yaik_amd._lib import lib
     if version == 1:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libyaik_v1check.so")
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.path.join(here, "csrc", "libyaik_v1check.so")
+        if not os.path.exists(path):                                       # normally built by __graft_entry__.build() / make -C yaik_amd/csrc
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(os.path.dirname(here), "yaik_amd", "csrc")], check=True)
         v1 = C.CDLL(path)
         select_kernel_version._keep = v1                                   # the library keeps a raw function pointer
         assert lib().yk_set_cross_check_launcher(C.cast(v1.yk_v1_launch, C.c_void_p)) == 0
