@@ -212,7 +212,9 @@ int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]);
  * 16 bytes: 7 gradient bitmaps | keep flags (1 byte per 16x16 tile, RGBA only) | per plane: tile defs (u16), nibbles.
  * sizes[0..6] bitmap bytes, sizes[7] keep bytes, sizes[8+2p] = nDefs(p), sizes[9+2p] = nNibbles(p), sizes[14] = total
  * bytes written.  One kernel packs all sections; the call returns after the stream has been synchronised, i.e. the buffer
- * is complete and may be handed to another runtime instance / RCCL.  cap >= yk_export_capacity. */
+ * is complete and may be handed to another runtime instance / RCCL.  cap >= yk_export_capacity.  The buffer is WRITTEN on the handle's
+ * stream: work other streams still have queued on it (its fill, a previous consumer) must have finished or be ordered before that stream
+ * (yk_stream_wait_for) -- the handle's stream is not ordered against any other. */
 size_t yk_export_capacity(const yk_ctx* c);
 int    yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[15]);
 /* The same without a host synchronisation, for pipelines that keep the size table on the device: devMeta16 (device, 16 x u64)

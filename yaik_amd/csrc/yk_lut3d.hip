@@ -11,8 +11,11 @@
 // results of the accepted tiles into the reference's streams in scan order.
 //
 // HBM layout of a pattern (built on the device by yk_lut_build_kernel): distance field u16[64^3] (the reference keeps int32; the largest
-// squared distance is 3 * 63^2), nearest-entry tables u8[4][64^3] for 6 / 5 / 4 / 3 bits, factor tables s16[4][3][64]: 1.5 MB per pattern.
-// Not on the timed path of bench.py; the search is gather-bound (<= 128 pixels x patterns x 48 orientations distance look-ups per tile).
+// squared distance is 3 * 63^2), nearest-entry tables u8[4][64^3] for 6 / 5 / 4 / 3 bits, factor tables s16[4][3][64], and the distance
+// field ONCE PER ORIENTATION, orientation-minor: orient[cell][48] = dist[orientation_m(cell)], 24 MB per pattern.  The scoring reads, for one
+// pixel, the 48 orientation distances of a pattern as 96 contiguous bytes (48 lanes, two cache lines) instead of 48 scattered 2-byte
+// gathers: with 288 GB of HBM the 1.5 GB a full 64-pattern bank takes is the cheap side of that trade (DESIGN 3.8 has the measurements).
+// Not on the timed path of bench.py.
 #include "yk_common.h"
 #include "yk_device.h"
 #include <vector>
@@ -21,8 +24,8 @@
 #define LUT_FACTOR 128                      // FACTOR, EncoderContext.cpp:22
 #define LUT_MAXPAT 64
 
-struct YkLutPattern { uint16_t* dist; uint8_t* pos; int16_t* fac; int count; };      // device pointers
-struct YkLutBank { const uint16_t* dist[LUT_MAXPAT]; const uint8_t* pos[LUT_MAXPAT]; const int16_t* fac[LUT_MAXPAT]; int nPat; };
+struct YkLutPattern { uint16_t* dist; uint16_t* orient; uint8_t* pos; int16_t* fac; int count; };      // device pointers
+struct YkLutBank { const uint16_t* orient[LUT_MAXPAT]; const uint8_t* pos[LUT_MAXPAT]; const int16_t* fac[LUT_MAXPAT]; int nPat; };
 struct YkLutState {
     YkLutPattern pat[LUT_MAXPAT]; int nPat = 0;
     YkLutBank* bankDev = nullptr;           // the table of pointers above, in HBM (too large for kernel arguments)
@@ -85,6 +88,17 @@ __global__ __launch_bounds__(256) void yk_lut_build_kernel(const uint8_t* __rest
     }
 }
 
+// orient[cell * 48 + m] = dist at the cell orientation m maps `cell` to (the index EvaluatePoint3D forms for entry m)
+__global__ __launch_bounds__(256) void yk_lut_orient_kernel(const uint16_t* __restrict__ dist, uint16_t* __restrict__ orient) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)LUT_CUBE * 48) return;
+    const int cell = (int)(i / 48), m = (int)(i - (size_t)cell * 48);
+    const int q[3] = { cell & 63, (cell >> 6) & 63, cell >> 12 };
+    const int perm = c_lutPerm[m], ax = perm & 3, ay = (perm >> 2) & 3, az = (perm >> 4) & 3;
+    const int fx = (m & 1) ? 63 - q[ax] : q[ax], fy = (m & 2) ? 63 - q[ay] : q[ay], fz = (m & 4) ? 63 - q[az] : q[az];
+    orient[i] = dist[fx + (fy << 6) + (fz << 12)];
+}
+
 struct LutGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow, mapId; };
 static LutGeo yk_lut_geo(int sx, int sy, int w) {
     LutGeo g; g.sx = sx; g.sy = sy;
@@ -105,13 +119,17 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
                                                             int w, int h, LutGeo g, const YkLutBank* __restrict__ bank, uint32_t* __restrict__ covCh32, size_t covStride,
                                                             int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap) {
     __shared__ int s_i64[128];                                              // normalised 6-bit coordinates x | y << 6 | z << 12, -1 = masked pixel
-    __shared__ int s_rgb[128];
     __shared__ int s_box[6], s_n;
-    __shared__ int s_sum[LUT_MAXPAT * 48];
-    __shared__ int s_mode[LUT_MAXPAT];
-    __shared__ int s_acc[LUT_MAXPAT][8];                                    // absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
+    // sized by the bank at launch (a 64-pattern bank needs 19 KB, the usual handful 2 KB: four more workgroups per CU)
+    extern __shared__ int s_dyn[];
+    const int nPatS = bank->nPat;
+    int* const s_sum = s_dyn;                                               // [nPat][48]
+    int* const s_mode = s_sum + nPatS * 48;                                 // [nPat]
+    int (*const s_acc)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPatS);   // [nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
+    int (*const s_part0)[8] = s_acc + nPatS;                                // the same per wave
+    int (*const s_part1)[8] = s_part0 + nPatS;
     __shared__ int s_best[4];                                               // pattern, orientation, bit mode, found
-    const int t = threadIdx.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;
+    const int t = threadIdx.x, NT = blockDim.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;      // NT = 128, or 64 for tiles of at most 64 pixels
     const uint32_t pos = blockIdx.x;
     const uint32_t blk = pos / (uint32_t)g.bitCount, tt = pos % (uint32_t)g.bitCount;
     const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
@@ -154,28 +172,34 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
             for (int c = 0; c < 3; c++) { const int n = d[c] ? (1 << 20) / d[c] : 0; const float f = __fdiv_rn((float)((v[c] - lo[c]) * n), 1048576.0f); q[c] = (int)__fmul_rn(f, 63.0f); }
             cell = q[0] | (q[1] << 6) | (q[2] << 12);
         }
-        s_i64[t] = cell; s_rgb[t] = v[0] | (v[1] << 8) | (v[2] << 16);
+        s_i64[t] = cell;
     }
     __syncthreads();
-    // EvaluatePoint3D: sum of the distance field over the tile's pixels for every (pattern, orientation)
-    for (int combo = t; combo < nPat * 48; combo += 128) {
-        const int k = combo / 48, m = combo - k * 48;
-        const uint16_t* __restrict__ dist = bank->dist[k];
-        const int perm = c_lutPerm[m], ax = perm & 3, ay = (perm >> 2) & 3, az = (perm >> 4) & 3;
-        int sum = 0;
-        for (int p = 0; p < nPix; p++) {
-            const int cell = s_i64[p];
-            if (cell < 0) continue;
-            const int q[3] = { cell & 63, (cell >> 6) & 63, cell >> 12 };
-            const int fx = (m & 1) ? 63 - q[ax] : q[ax], fy = (m & 2) ? 63 - q[ay] : q[ay], fz = (m & 4) ? 63 - q[az] : q[az];
-            sum += dist[fx + (fy << 6) + (fz << 12)];
+    // EvaluatePoint3D: sum of the distance field over the tile's pixels for every (pattern, orientation).  Threads 0..95 = two patterns x 48
+    // orientations per round; for one pixel the 48 lanes of a pattern read 96 contiguous bytes of its orientation-minor table.
+    const int perRound = NT >= 96 ? 2 : 1;
+    for (int k0 = 0; k0 < nPat; k0 += perRound) {
+        const int k = k0 + t / 48, m = t % 48;
+        if (t < 48 * perRound && k < nPat) {
+            const uint16_t* __restrict__ orient = bank->orient[k];
+            // branch-free and eight pixels at a time: the loads of a thread are independent, a loop of dependent-latency round trips (one
+            // load per iteration behind a test) was the whole cost of this kernel; s_i64 holds -1 beyond the tile's pixels
+            int sum = 0;
+            for (int p0 = 0; p0 < nPix; p0 += 8) {
+                int cell[8]; uint32_t d8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) cell[j] = s_i64[p0 + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) d8[j] = orient[(size_t)max(cell[j], 0) * 48 + m];
+#pragma unroll
+                for (int j = 0; j < 8; j++) sum += cell[j] >= 0 ? (int)d8[j] : 0;
+            }
+            s_sum[k * 48 + m] = sum;
         }
-        s_sum[combo] = sum;
     }
-    for (int k = t; k < nPat; k += 128) { for (int j = 0; j < 8; j++) s_acc[k][j] = 0; }
     __syncthreads();
     // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float
-    for (int k = t; k < nPat; k += 128) {
+    for (int k = t; k < nPat; k += NT) {
         int res = -1; float minScore = 999999999.0f;
         const float den = __fmul_rn((float)pixels, 1024.0f);
         for (int f = 0; f < 48; f++) { const float avg = __fdiv_rn((float)s_sum[k * 48 + f], den); if (avg < minScore) { minScore = avg; res = f; } }
@@ -184,15 +208,18 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     __syncthreads();
     // computeValues3D for every pattern at its best orientation: per pixel the entry at 6 / 5 / 4 / 3 bits and its worst channel error.
     // Its early exit (all four depths rejected at the end of a row) returns what the full pass returns, so the sums are order-free.
+    // the pixel's position in the box (:5871-5887), the same for every pattern and depth; lanes without a pixel sit on the box's low corner
+    float relp[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float rel = live ? (float)(v[c] - lo[c]) : 0.0f;
+        if (d[c]) rel = __fdiv_rn(rel, (float)d[c]);
+        relp[c] = __fmul_rn(rel, 63.0f);
+    }
     auto entry = [&](int k, int mode, int depth /*0 = 6 bit*/, int& idx, int (&col)[3]) {
         int m[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float rel = (float)(v[c] - lo[c]);
-            if (d[c]) rel = __fdiv_rn(rel, (float)d[c]);
-            rel = __fmul_rn(rel, 63.0f);
-            m[c] = ((mode >> c) & 1) ? (int)__fsub_rn(63.0f, rel) : (int)rel;
-        }
+        for (int c = 0; c < 3; c++) m[c] = ((mode >> c) & 1) ? (int)__fsub_rn(63.0f, relp[c]) : (int)relp[c];
         yk_lut_swap(mode >> 3, m[0], m[1], m[2]);
         idx = bank->pos[k][(size_t)depth * LUT_CUBE + (m[0] + m[1] * 64 + (m[2] << 12))];
         const int16_t* __restrict__ fac = bank->fac[k] + depth * 3 * 64;
@@ -203,19 +230,42 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
 #pragma unroll
         for (int c = 0; c < 3; c++) col[c] = lo[c] + (co[c] * d[c]) / LUT_FACTOR;
     };
-    if (live) {
-        for (int k = 0; k < nPat; k++) {
+    // per pattern: the four depths' worst-channel errors of this pixel, summed over the tile with wave reductions (two 16-bit sums per
+    // shuffle word: a tile holds at most 128 pixels of error <= 255) and ballots for the ">5" counts; LDS atomics on eight shared words
+    // per pattern serialised all 64 lanes of a wave and were the larger half of this kernel's time
+    {
+        const int wv = t >> 6;
+        auto evalPattern = [&](const int k, int (&w4)[4]) {
             const int mode = s_mode[k];
 #pragma unroll
             for (int depth = 0; depth < 4; depth++) {
                 int idx, col[3];
                 entry(k, mode, depth, idx, col);
-                const int worst = max(max(abs(col[0] - v[0]), abs(col[1] - v[1])), abs(col[2] - v[2]));
-                atomicAdd(&s_acc[k][depth], worst);
-                if (worst > 5) atomicAdd(&s_acc[k][4 + depth], 1);
+                w4[depth] = live ? max(max(abs(col[0] - v[0]), abs(col[1] - v[1])), abs(col[2] - v[2])) : 0;
             }
+        };
+        auto reducePattern = [&](const int k, const int (&w4)[4]) {
+            int s01 = w4[0] | (w4[1] << 16), s23 = w4[2] | (w4[3] << 16);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { s01 += __shfl_xor(s01, off); s23 += __shfl_xor(s23, off); }
+            const int c0 = __popcll(__ballot(w4[0] > 5)), c1 = __popcll(__ballot(w4[1] > 5)), c2 = __popcll(__ballot(w4[2] > 5)), c3 = __popcll(__ballot(w4[3] > 5));
+            if ((t & 63) == 0) {
+                int* a = (wv ? s_part1 : s_part0)[k];
+                a[0] = s01 & 0xFFFF; a[1] = s01 >> 16; a[2] = s23 & 0xFFFF; a[3] = s23 >> 16; a[4] = c0; a[5] = c1; a[6] = c2; a[7] = c3;
+            }
+        };
+        // two patterns per round: their eight look-up chains (cell -> entry -> three factors) are in flight together.  Lanes without a pixel
+        // run the same loads on a harmless cell (every lane of a wave takes part in the reductions) and contribute 0.
+        for (int k = 0; k < nPat; k += 2) {
+            int wa[4], wb[4] = { 0, 0, 0, 0 };
+            evalPattern(k, wa);
+            if (k + 1 < nPat) evalPattern(k + 1, wb);
+            reducePattern(k, wa);
+            if (k + 1 < nPat) reducePattern(k + 1, wb);
         }
     }
+    __syncthreads();
+    for (int i = t; i < nPat * 8; i += NT) s_acc[i >> 3][i & 7] = s_part0[i >> 3][i & 7] + (NT > 64 ? s_part1[i >> 3][i & 7] : 0);
     __syncthreads();
     if (t == 0) {
         // :6066-6069 (lowest depth that is not rejected, a depth is rejected when more than 3 pixels are off by more than 5) and the choice
@@ -245,7 +295,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     if (t == 0) s_w0 = __popcll(bal);
     __syncthreads();
     if (live) {
-        const int rank = __popcll(bal & ((1ULL << (t & 63)) - 1ULL)) + (t >= 64 ? s_w0 : 0);
+        const int rank = __popcll(bal & ((1ULL << (t & 63)) - 1ULL)) + (t >= 64 ? s_w0 : 0);      // s_w0: live pixels of the first wave
         int idx, col[3];
         entry(s_best[0], s_best[1], 3 - s_best[2], idx, col);
         slotIdx[(size_t)pos * nPix + rank] = (uint8_t)idx;
@@ -309,7 +359,7 @@ __global__ __launch_bounds__(1024) void yk_lut_emit_kernel(const LutSlot* __rest
 static void yk_lut_release(yk_ctx* c) {
     YkLutState* S = c->lut; if (!S) return;
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    for (int k = 0; k < S->nPat; k++) { F(S->pat[k].dist); F(S->pat[k].pos); F(S->pat[k].fac); }
+    for (int k = 0; k < S->nPat; k++) { F(S->pat[k].dist); F(S->pat[k].orient); F(S->pat[k].pos); F(S->pat[k].fac); }
     F(S->bankDev); F(S->tileType); F(S->color);
     for (auto& p : S->idx) F(p);
     for (auto& p : S->map) F(p);
@@ -355,6 +405,7 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     YkLutPattern& P = S->pat[S->nPat];
     P.count = count;
     YK_HIP(c, hipMalloc(&P.dist, LUT_CUBE * sizeof(uint16_t)));
+    YK_HIP(c, hipMalloc(&P.orient, (size_t)LUT_CUBE * 48 * sizeof(uint16_t)));
     YK_HIP(c, hipMalloc(&P.pos, 4 * LUT_CUBE));
     YK_HIP(c, hipMalloc(&P.fac, sizeof fac));
     uint8_t* dPts = nullptr;
@@ -362,13 +413,14 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     YK_HIP(c, hipMemcpyAsync(dPts, pts, (size_t)count * 3, hipMemcpyHostToDevice, c->stream));
     YK_HIP(c, hipMemcpyAsync(P.fac, fac, sizeof fac, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(yk_lut_build_kernel, dim3(LUT_CUBE / 256), dim3(256), 0, c->stream, dPts, count, P.dist, P.pos);
+    hipLaunchKernelGGL(yk_lut_orient_kernel, dim3((unsigned)(((size_t)LUT_CUBE * 48 + 255) / 256)), dim3(256), 0, c->stream, P.dist, P.orient);
     YK_HIP(c, hipGetLastError());
     YK_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(dPts);
     if (index) *index = S->nPat;
     S->nPat++;
     YkLutBank bank = {};
-    for (int k = 0; k < S->nPat; k++) { bank.dist[k] = S->pat[k].dist; bank.pos[k] = S->pat[k].pos; bank.fac[k] = S->pat[k].fac; }
+    for (int k = 0; k < S->nPat; k++) { bank.orient[k] = S->pat[k].orient; bank.pos[k] = S->pat[k].pos; bank.fac[k] = S->pat[k].fac; }
     bank.nPat = S->nPat;
     if (!S->bankDev) YK_HIP(c, hipMalloc(&S->bankDev, sizeof(YkLutBank)));
     YK_HIP(c, hipMemcpy(S->bankDev, &bank, sizeof bank, hipMemcpyHostToDevice));
@@ -427,7 +479,7 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     YK_HIP(c, hipMalloc(&slotIdx, nSlots * nPix));
     YK_HIP(c, hipMalloc(&sums, (5 * nb + 16) * sizeof(uint32_t)));
     { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(128), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
+    hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 24) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
                        S->bankDev, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
     { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_lut_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, slots, nSlots, sums, nb);

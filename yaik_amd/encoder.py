@@ -296,12 +296,17 @@ class HipTileEncoder:
     def export_tile_maps(self, dev_buffer) -> np.ndarray:
         """dev_buffer: torch uint8 cuda tensor of >= export_capacity() bytes. Returns the 15 section sizes."""
         sizes = np.zeros(15, dtype=np.uint64)
+        # hand-over fence (see set_image): whatever torch still has queued on the buffer (its allocation fill, an earlier consumer) must be
+        # done before the handle's own stream writes into it -- the two streams are not ordered against each other
+        import torch
+        torch.cuda.current_stream(dev_buffer.device).synchronize()
         _chk(self._h, lib().yk_export_tile_maps(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(), sizes.ctypes.data))
         return sizes
 
     def export_tile_maps_async(self, dev_buffer, dev_meta16, consumer_stream: int = 0) -> None:
         """No host synchronisation: dev_meta16 (torch int64[16] cuda tensor) receives {total bytes, sizes[0..14]}; work queued
-        afterwards on `consumer_stream` (a hipStream_t of the same runtime, 0 = null stream) sees buffer and table complete."""
+        afterwards on `consumer_stream` (a hipStream_t of the same runtime, 0 = null stream) sees buffer and table complete.
+        The caller orders EARLIER work on the two buffers before the handle's stream itself (yk_stream_wait_for, or buffers that are idle)."""
         _chk(self._h, lib().yk_export_tile_maps_async(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(),
                                                       C.c_void_p(dev_meta16.data_ptr()), C.c_void_p(consumer_stream)))
 
