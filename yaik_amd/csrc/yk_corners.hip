@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void yk_corner_owner_kernel(const CornerPlan p
     // One thread per bitmap byte (8 slots of one swizzle block: the block's coordinates are computed once, see yk_corner_stream_kernel).
     // Measured alternatives on the 8192x8192 bench frame (131 k accepted 16x16 tiles): one thread per word 41 us, per byte 41 us, per byte
     // with the atomics of corners a lower-positioned neighbour tile of the same pass also touches left out 47 us, per slot with that
-    // filter 51 us (16 us of it just starting 10.7 M threads): neither the atomics nor the serial tile loop is the cost.
+    // filter 51 us (16 us of it just starting 10.7 M threads).  What does pay is the filter WITHOUT any look-up: among the 8 tiles of the
+    // thread's own byte (15 atomics instead of 32 for a dense 2 x 4 group of 16x16 tiles).
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= pl.wordStart[7] * 4u) return;
     const int pass = yk_plan_find(pl.wordStart, gi >> 2);
@@ -65,9 +66,17 @@ __global__ __launch_bounds__(256) void yk_corner_owner_kernel(const CornerPlan p
         const int x = bx0 + (int)((t & (uint32_t)(g.tilesPerRow - 1)) << g.sx), y = by0 + (int)((t >> tprShift) << g.sy);
         const int lx = x >> 2, ly = y >> 2;
         const uint32_t key = ((uint32_t)pass << 27) | ((pos0 + (uint32_t)k) << 2);
-        atomicMin(&owner[(size_t)ly * latW + lx], key | 0u);
-        atomicMin(&owner[(size_t)ly * latW + lx + dx], key | 1u);
-        atomicMin(&owner[(size_t)(ly + dy) * latW + lx], key | 2u);
+        // a corner an EARLIER tile of this same byte also touches belongs to that tile (smaller scan position): no atomic for it.  The byte
+        // is one row of 8 tiles, or two rows of 4 when the swizzle block is 4 tiles wide: left, upper, upper-left, upper-right neighbours.
+        const int col = (int)(t & (uint32_t)(g.tilesPerRow - 1));
+        const bool two = g.tilesPerRow == 4;
+        const bool left = k >= 1 && col != 0 && ((byte >> (k - 1)) & 1u);
+        const bool up = two && k >= 4 && ((byte >> (k - 4)) & 1u);
+        const bool upLeft = two && k >= 5 && col != 0 && ((byte >> (k - 5)) & 1u);
+        const bool upRight = two && k >= 4 && col != 3 && ((byte >> (k - 3)) & 1u);
+        if (!(left || up || upLeft)) atomicMin(&owner[(size_t)ly * latW + lx], key | 0u);
+        if (!(up || upRight)) atomicMin(&owner[(size_t)ly * latW + lx + dx], key | 1u);
+        if (!left) atomicMin(&owner[(size_t)(ly + dy) * latW + lx], key | 2u);
         atomicMin(&owner[(size_t)(ly + dy) * latW + lx + dx], key | 3u);
     }
 }
@@ -129,30 +138,64 @@ __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const CornerPlan
     }
     uint32_t tot;
     const uint32_t ex = yk_block_exscan(cnt, s_tmp, &tot);
-    if (!cnt) return;
-    uint32_t off = (blockSums[blockIdx.x] - blockSums[pl.blockStart[pass]] + ex) * 3u;
+    // The workgroup's colours are one contiguous run of the pass's stream: they are collected in LDS and leave as 4-byte stores (three
+    // single-byte stores per colour from scattered lanes were most of this kernel's time); a workgroup with more colours than the LDS
+    // image holds (possible only with many small tiles owning all four corners) stores directly.
+    constexpr uint32_t kCap = 8192;                                          // colours
+    __shared__ uint32_t s_out[kCap * 3 / 4];
+    __shared__ uint32_t s_li[kCap];                                          // lattice index of the workgroup's j-th colour, in stream order
+    const uint32_t blockOff = (blockSums[blockIdx.x] - blockSums[pl.blockStart[pass]]) * 3u;
     uint8_t* __restrict__ out = out0 + region * pass;
+    const bool viaLds = tot <= kCap;
+    uint8_t* const s_bytes = reinterpret_cast<uint8_t*>(s_out);
+    auto colour = [&](const uint32_t li, const uint32_t j, const bool toLds) {   // j-th colour of the workgroup: lattice point li
+        const int ly = (int)(li / (uint32_t)latW), lx = (int)(li - (uint32_t)ly * (uint32_t)latW);
+        // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
+        const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
+        // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
+        if (ly == 0) edgeIdx[lx] = blockOff / 3u + j;
+        if (ly == latH - 1) edgeIdx[latW + lx] = blockOff / 3u + j;
+        const int v[3] = { pR[src], pG[src], pB[src] };
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (!own[k]) continue;
+        for (int ch = 0; ch < 3; ch++) {
+            const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                           // Round6 (:3183)
+            const uint8_t q = (uint8_t)((r6 * 250 + 127) / 255);                                   // CompressF(.,colorCompressionQuad=250) (:3191)
+            if (toLds) s_bytes[j * 3u + ch] = q; else out[blockOff + j * 3u + ch] = q;
+        }
+    };
+    // phase 1: every thread lists the lattice points it owns at its place in the run (scan order); phase 2: one thread per colour, so the
+    // three sample loads of the workgroup's colours are all in flight together instead of one owned corner after the other per thread
+    if (cnt) {
+        uint32_t j = ex;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
-            if (!((own[k] >> c4) & 1u)) continue;
-            const int lx = (tx[k] >> 2) + ((c4 & 1) ? dx : 0), ly = (ty[k] >> 2) + ((c4 & 2) ? dy : 0);
-            // GetPixelValue clamp (:3853-3856); a stripe's bottom lattice row is its halo row (= the next stripe's first row)
-            const size_t src = (size_t)min(ly * 4, hAvail - 1) * strideElems + min(lx * 4, w - 1);
-            // stripes: where along this pass's stream the first and last lattice rows were emitted (root-side de-duplication)
-            if (ly == 0) edgeIdx[lx] = off / 3u;
-            if (ly == latH - 1) edgeIdx[latW + lx] = off / 3u;
-            const int v[3] = { pR[src], pG[src], pB[src] };
+        for (int k = 0; k < 8; k++) {
+            if (!own[k]) continue;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int r6 = (v[ch] & ~3) | (v[ch] >> 6);                                       // Round6 (:3183)
-                out[off + ch] = (uint8_t)((r6 * 250 + 127) / 255);                                 // CompressF(.,colorCompressionQuad=250) (:3191)
+            for (int c4 = 0; c4 < 4; c4++) {
+                if (!((own[k] >> c4) & 1u)) continue;
+                const uint32_t li = (uint32_t)((ty[k] >> 2) + ((c4 & 2) ? dy : 0)) * (uint32_t)latW + (uint32_t)((tx[k] >> 2) + ((c4 & 1) ? dx : 0));
+                if (viaLds) s_li[j] = li; else colour(li, j, false);
+                j++;
             }
-            off += 3;
         }
     }
+    if (!viaLds) return;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tot; j += 1024) colour(s_li[j], j, true);
+    __syncthreads();
+    // copy out: unaligned head bytes, whole words, tail bytes (the run starts at an arbitrary byte of the stream)
+    const uint32_t outBytes = tot * 3u;
+    uint8_t* const dst = out + blockOff;
+    const uint32_t head = min(outBytes, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+    if (threadIdx.x < head) dst[threadIdx.x] = s_bytes[threadIdx.x];
+    const uint32_t nWords = (outBytes - head) >> 2;
+    for (uint32_t i = threadIdx.x; i < nWords; i += 1024) {
+        const uint32_t b = head + i * 4u;                                    // LDS side is unaligned by `head`: assemble from bytes
+        const uint32_t wv = (uint32_t)s_bytes[b] | ((uint32_t)s_bytes[b + 1] << 8) | ((uint32_t)s_bytes[b + 2] << 16) | ((uint32_t)s_bytes[b + 3] << 24);
+        *reinterpret_cast<uint32_t*>(dst + b) = wv;
+    }
+    const uint32_t tail0 = head + nWords * 4u;
+    if (threadIdx.x < outBytes - tail0) dst[tail0 + threadIdx.x] = s_bytes[tail0 + threadIdx.x];
 }
 
 // exclusive prefix of all block sums in place (one workgroup: thread t owns a run of consecutive blocks) + the corners per pass
