@@ -101,14 +101,23 @@ __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __re
     }
     __syncthreads();
     const int nT = __popc(bits);
+    // the four corner colours of the word's tiles, once (every run of a tile used to fetch them again: 4 byte loads per 8-byte store)
+    __shared__ uint8_t s_c[32][3][4];
+    for (int i = threadIdx.x; i < nT * 12; i += 256) {
+        const int k = i / 12, e = i - 12 * k, c = e >> 2, q = e & 3;
+        const int x = s_xy[k][0], y = s_xy[k][1];
+        if (x < 0) continue;
+        const size_t li = (size_t)((y >> 2) + ((q & 2) ? dy : 0)) * latW + (x >> 2) + ((q & 1) ? dx : 0);
+        s_c[k][c][q] = mapRGB[li * 3 + c];
+    }
+    __syncthreads();
     for (int item = threadIdx.x; item < nT * nEl; item += 256) {
         const int ck = item >> lgPer, k = ck / 3, c = ck - 3 * k;               // tile of the word, channel
         const int x = s_xy[k][0], y = s_xy[k][1];
         if (x < 0) continue;
         const int r = item & (perCh - 1), ty = r >> lgGpr, gx = (r & (gpr - 1)) * GW;
-        const size_t l0 = (size_t)(y >> 2) * latW + (x >> 2);
-        const int TL = mapRGB[l0 * 3 + c], TR = mapRGB[(l0 + dx) * 3 + c];
-        const int BL = mapRGB[(l0 + (size_t)dy * latW) * 3 + c], BR = mapRGB[(l0 + (size_t)dy * latW + dx) * 3 + c];
+        const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&s_c[k][c][0]);
+        const int TL = c4 & 255, TR = (c4 >> 8) & 255, BL = (c4 >> 16) & 255, BR = c4 >> 24;
         const int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
         int v = L * (TX - gx) + R * gx;                                         // numerator at the first pixel of the run, + (R - L) per pixel
         const int xx = x + gx, yy = y + ty;
@@ -122,16 +131,20 @@ __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __re
             *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
         } else *reinterpret_cast<uint32_t*>(o) = lo;
     }
-    // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953)
-    const int lgCells = (g.sx - 2) + (g.sy - 2);
-    for (int item = threadIdx.x; item < (nT << lgCells); item += 256) {
-        const int k = item >> lgCells, e = item & ((1 << lgCells) - 1);
+    // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953).  A tile's
+    // cells lie in at most two mask bytes (one per pair of cell rows; tiles are at most 4 cells wide and aligned to their size): one
+    // atomic per byte with all of the tile's bits in it (one per CELL was 16 device-scope atomics per 16x16 tile: most of this kernel)
+    for (int item = threadIdx.x; item < nT * 2; item += 256) {
+        const int k = item >> 1, j = item & 1;
         const int x = s_xy[k][0], y = s_xy[k][1];
         if (x < 0) continue;
-        const int cx = (x >> 2) + (e & (dx - 1)), cy = (y >> 2) + (e >> (g.sx - 2));
-        const size_t byteIdx = (size_t)(cx >> 2) + (size_t)(cy >> 1) * stride4;
-        const uint32_t bit = (uint32_t)((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
-        atomicOr(&tile4[byteIdx >> 2], 1u << (bit + 8 * (byteIdx & 3)));
+        const int cx0 = x >> 2, cy0 = y >> 2, br = (cy0 >> 1) + j;                // byte row
+        if (br > ((cy0 + dy - 1) >> 1)) continue;
+        uint32_t m = 0;
+        for (int cy = max(cy0, br * 2); cy < min(cy0 + dy, br * 2 + 2); cy++)
+            for (int cx = cx0; cx < cx0 + dx; cx++) m |= 1u << ((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+        const size_t byteIdx = (size_t)(cx0 >> 2) + (size_t)br * stride4;
+        atomicOr(&tile4[byteIdx >> 2], m << (8 * (byteIdx & 3)));
     }
 }
 
