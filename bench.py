@@ -301,6 +301,14 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
                    "collective_backend": (dist.get_backend() if world > 1 else None), "collective_world_size": (dist.get_world_size() if world > 1 else 1)},
         "rank0_kernel_ms": {k: round(v, 4) for k, v in kms.items()},
     }
+    # roofline of the dominant kernel on rank 0's stripe: its algorithmic bytes (three int32 samples per owned pixel + the stripe's bitmaps,
+    # tile definitions and nibbles) over the event-timed duration of yk_encode2_kernel
+    nd_nn = [enc.range_streams(p) for p in range(3)] if enc else []
+    out_bytes = sum(2 * d.size + nb.size for d, nb, _ in nd_nn) + (sum(enc.gradient_bitmap(p).size for p in range(7)) if enc else 0)
+    alg = 12 * W * int(h) + out_bytes
+    achieved = alg / (kms["encode"] * 1e-3) / 1e9 if kms["encode"] > 0 else 0.0
+    result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                          "traffic": None, "kernel": "yk_encode2_kernel (rank 0's stripe)", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg)}
     if gather_check is not None:
         result["gather_check"] = gather_check
     print(json.dumps(result))
