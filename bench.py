@@ -157,7 +157,7 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         cand = int((~cov).sum()) * 16                         # pixels of tiles with anything left to code, an upper bound of what the passes read
         alg = 12 * cand * 6                                   # every pass reads the three int32 samples of its candidate tiles' pixels once
         kname, kms = "yk_lut_search_kernel (6 tile shapes)", per[6]
-        note = (f"gather-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations distance-field look-ups per candidate tile; "
+        note = (f"VALU-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations x 8 points squared distances (v_dot4_i32_i8) per candidate tile; "
                 f"{lut_matched[0]} tiles matched on this frame; algorithmic bytes = the candidate tiles' samples once per pass")
     else:
         pixn = uncovered * 3

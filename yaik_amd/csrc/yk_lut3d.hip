@@ -11,10 +11,9 @@
 // results of the accepted tiles into the reference's streams in scan order.
 //
 // HBM layout of a pattern (built on the device by yk_lut_build_kernel): distance field u16[64^3] (the reference keeps int32; the largest
-// squared distance is 3 * 63^2), nearest-entry tables u8[4][64^3] for 6 / 5 / 4 / 3 bits, factor tables s16[4][3][64], and the distance
-// field ONCE PER ORIENTATION, orientation-minor: orient[cell][48] = dist[orientation_m(cell)], 24 MB per pattern.  The scoring reads, for one
-// pixel, the 48 orientation distances of a pattern as 96 contiguous bytes (48 lanes, two cache lines) instead of 48 scattered 2-byte
-// gathers: with 288 GB of HBM the 1.5 GB a full 64-pattern bank takes is the cheap side of that trade (DESIGN 3.8 has the measurements).
+// squared distance is 3 * 63^2; exported for the parity tests, the search does not read it), nearest-entry tables u8[4][64^3] for 6 / 5 / 4 / 3
+// bits, factor tables s16[4][3][64], and 48 x 8 transformed subset points (yk_lut_point_table, 3 KB) from which the scoring computes the
+// distances with v_dot4_i32_i8 instead of reading them (DESIGN 3.8 has the measurements of both forms).
 // Not on the timed path of bench.py.
 #include "yk_common.h"
 #include "yk_device.h"
@@ -24,21 +23,28 @@
 #define LUT_FACTOR 128                      // FACTOR, EncoderContext.cpp:22
 #define LUT_MAXPAT 64
 
-struct YkLutPattern { uint16_t* dist; uint16_t* orient; uint8_t* pos; int16_t* fac; int count; };      // device pointers
-struct YkLutBank { const uint16_t* orient[LUT_MAXPAT]; const uint8_t* pos[LUT_MAXPAT]; const int16_t* fac[LUT_MAXPAT]; int nPat; };
+struct YkLutPattern { uint16_t* dist; uint32_t* pos; short4* fac; int count; };      // device pointers
+// ptab[(pattern * 48 + orientation) * 8 + j] = the j-th point of the pattern's 3-bit subset as that orientation sees it (yk_lut_point_table)
+// pos[pattern * 64^3 + cell] = the cell's nearest entry at 6 | 5 << 8 | 4 << 16 | 3 << 24 bits (one gather serves the four depths: the gathers into
+// these 1 MB tables are what the search waits for); fac[(pattern * 4 + depth) * 64 + entry] = the entry's three factors (x, y, z, 0).  One allocation
+// per table for the whole bank, passed as kernel arguments: no pointer per pattern to fetch first.
+struct YkLutBank { const uint2* ptab; const uint32_t* pos; const short4* fac; int nPat; };
 struct YkLutState {
     YkLutPattern pat[LUT_MAXPAT]; int nPat = 0;
-    YkLutBank* bankDev = nullptr;           // the table of pointers above, in HBM (too large for kernel arguments)
+    uint2* ptab = nullptr;                  // [LUT_MAXPAT][48][8], 192 KB
+    uint32_t* posAll = nullptr;             // [LUT_MAXPAT][64^3], 64 MB (allocated with the first pattern)
+    short4* facAll = nullptr;               // [LUT_MAXPAT][4][64]
     bool started = false;
     // corr3D_* streams (StartCorrelationSearch :7316-7364), device
     uint16_t* tileType = nullptr; uint8_t* color = nullptr; uint8_t* idx[4] = {}; uint8_t* map[6] = {};
     size_t nType = 0, nColor = 0, nIdx[4] = {}, mapBytes[6] = {};
-    size_t capTiles = 0, capPix = 0;
+    size_t capTiles = 0, capPix = 0; int capW = 0, capH = 0;
+    // per-pass scratch, sized for the 4x4 pass and kept across passes and searches
+    struct LutSlot* slots = nullptr; uint8_t* slotIdx = nullptr; uint32_t* sums = nullptr;
 };
 
 // the 48 orientations of EvaluatePoint3D: its axis swap of group n >> 3 is applied to the RUNNING x, y, z on every iteration of its loop
 // over n (encoder/EncoderContext.h:629-686), so entry n is a cumulative permutation; table[n] = source axis of x | y << 2 | z << 4
-__constant__ uint8_t c_lutPerm[48];
 static void yk_lut_perm_table(uint8_t out[48]) {
     int a[3] = { 0, 1, 2 };
     for (int n = 0; n < 48; n++) {
@@ -54,27 +60,24 @@ static void yk_lut_perm_table(uint8_t out[48]) {
         out[n] = (uint8_t)(a[0] | (a[1] << 2) | (a[2] << 4));
     }
 }
-__device__ __forceinline__ void yk_lut_swap(int mode, int& x, int& y, int& z) {            // swap3D (:5314-5354), not cumulative
-    int t;
-    switch (mode) {
-    case 1: t = z; z = y; y = t; break;
-    case 2: t = x; x = y; y = t; break;
-    case 3: t = x; x = y; y = z; z = t; break;
-    case 4: t = y; y = x; x = z; z = t; break;
-    case 5: t = x; x = z; z = t; break;
-    default: break;
-    }
+__device__ __forceinline__ void yk_lut_swap(int mode, int& x, int& y, int& z) {            // swap3D (:5314-5354), not cumulative; branch-free: lanes of a wave differ
+    // 0: (x,y,z)  1: (x,z,y)  2: (y,x,z)  3: (y,z,x)  4: (z,x,y)  5: (z,y,x)
+    const int nx = (mode == 2 || mode == 3) ? y : (mode >= 4 ? z : x);
+    const int ny = (mode == 1 || mode == 3) ? z : ((mode == 2 || mode == 4) ? x : y);
+    const int nz = (mode == 1 || mode == 4) ? y : ((mode == 3 || mode == 5) ? x : z);
+    x = nx; y = ny; z = nz;
 }
 
 // Set3DPointCloud's scan of the cube (:4786-4813): nearest point of every cell among every (1 << step)-th point, first minimum wins; the
 // distance field is overwritten by every step, i.e. it ends as the distance to the nearest point of the 3-bit subset
-__global__ __launch_bounds__(256) void yk_lut_build_kernel(const uint8_t* __restrict__ pts, int count, uint16_t* __restrict__ dist, uint8_t* __restrict__ pos) {
+__global__ __launch_bounds__(256) void yk_lut_build_kernel(const uint8_t* __restrict__ pts, int count, uint16_t* __restrict__ dist, uint32_t* __restrict__ pos) {
     __shared__ uint8_t s_pts[64 * 3];
     if (threadIdx.x < count * 3) s_pts[threadIdx.x] = pts[threadIdx.x];
     __syncthreads();
     const int i3 = blockIdx.x * blockDim.x + threadIdx.x;
     if (i3 >= LUT_CUBE) return;
     const int x = i3 & 63, y = (i3 >> 6) & 63, z = i3 >> 12;
+    uint32_t entries = 0;                                                   // the cell's nearest entry at 6 / 5 / 4 / 3 bits, one byte each
 #pragma unroll
     for (int step = 0; step < 4; step++) {
         int minDist = 999999999, best = 0;
@@ -83,21 +86,48 @@ __global__ __launch_bounds__(256) void yk_lut_build_kernel(const uint8_t* __rest
             const int d = dx * dx + dy * dy + dz * dz;
             if (d < minDist) { minDist = d; best = p >> step; }
         }
-        pos[(size_t)step * LUT_CUBE + i3] = (uint8_t)best;
+        entries |= (uint32_t)best << (8 * step);
         if (step == 3) dist[i3] = (uint16_t)minDist;
+    }
+    pos[i3] = entries;
+}
+
+// The scoring of EvaluatePoint3D sums, over a tile's pixels, the distance field at the cell orientation m maps the pixel's cell c to:
+// T_m(c) = (f1(c[ax]), f2(c[ay]), f4(c[az])) with the axis permutation (ax, ay, az) of yk_lut_perm_table and f_b(v) = (m & b) ? 63 - v : v.
+// The field is the squared distance to the nearest point of the 3-bit subset (<= 8 points, see yk_lut_build_kernel), and
+// |T_m(c) - p|^2 = |c - p'|^2 with p'[ax] = f1(p.x), p'[ay] = f2(p.y), p'[az] = f4(p.z): instead of 48 permuted look-ups into a 64^3 table per
+// pixel the search evaluates min_j (|p'_j|^2 - 2 c.p'_j) + |c|^2 directly, one v_dot4_i32_i8 per (pixel, point).  Entry = { bytes (-2p'x, -2p'y,
+// -2p'z, 0) as int8, |p'|^2 }; subsets of fewer than 8 points repeat point 0 (the minimum does not change).
+static void yk_lut_point_table(const uint8_t* pts, int count, uint2 out[48 * 8]) {
+    uint8_t perm[48]; yk_lut_perm_table(perm);
+    for (int m = 0; m < 48; m++) {
+        const int ax = perm[m] & 3, ay = (perm[m] >> 2) & 3, az = (perm[m] >> 4) & 3;
+        for (int j = 0; j < 8; j++) {
+            const int p = (j * 8 < count) ? j * 8 : 0;
+            int q[3];
+            q[ax] = (m & 1) ? 63 - pts[p * 3] : pts[p * 3];
+            q[ay] = (m & 2) ? 63 - pts[p * 3 + 1] : pts[p * 3 + 1];
+            q[az] = (m & 4) ? 63 - pts[p * 3 + 2] : pts[p * 3 + 2];
+            out[m * 8 + j].x = (uint32_t)(uint8_t)(-2 * q[0]) | ((uint32_t)(uint8_t)(-2 * q[1]) << 8) | ((uint32_t)(uint8_t)(-2 * q[2]) << 16);
+            out[m * 8 + j].y = (uint32_t)(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        }
     }
 }
 
-// orient[cell * 48 + m] = dist at the cell orientation m maps `cell` to (the index EvaluatePoint3D forms for entry m)
-__global__ __launch_bounds__(256) void yk_lut_orient_kernel(const uint16_t* __restrict__ dist, uint16_t* __restrict__ orient) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)LUT_CUBE * 48) return;
-    const int cell = (int)(i / 48), m = (int)(i - (size_t)cell * 48);
-    const int q[3] = { cell & 63, (cell >> 6) & 63, cell >> 12 };
-    const int perm = c_lutPerm[m], ax = perm & 3, ay = (perm >> 2) & 3, az = (perm >> 4) & 3;
-    const int fx = (m & 1) ? 63 - q[ax] : q[ax], fy = (m & 2) ? 63 - q[ay] : q[ay], fz = (m & 4) ? 63 - q[az] : q[az];
-    orient[i] = dist[fx + (fy << 6) + (fz << 12)];
+// a.b + c on four signed bytes.  The builtin (__builtin_amdgcn_sdot4) is selected as v_dot4c (accumulator = destination) behind a v_mov of c;
+// the three-source form takes c where it is: one VALU instruction per (pixel, point) instead of two.
+__device__ __forceinline__ int yk_dot4(int a, int b, int c) {
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
+
+#ifndef YK_LUT_ABLATE
+#define YK_LUT_ABLATE 0                     // timing experiments only (tools/prof_lut.sh): 1 = no scoring, 2 = no entry evaluation, 3 / 4 / 5 = leave after the box / the scoring / the entry evaluation (nothing is matched)
+#endif
+typedef unsigned short y_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t yk_us2_bits(y_us2 a) { return (uint32_t)a.x | ((uint32_t)a.y << 16); }
+__device__ __forceinline__ y_us2 yk_us2_from(int b) { y_us2 r = { (unsigned short)((uint32_t)b & 0xFFFFu), (unsigned short)((uint32_t)b >> 16) }; return r; }
 
 struct LutGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow, mapId; };
 static LutGeo yk_lut_geo(int sx, int sy, int w) {
@@ -113,48 +143,66 @@ static LutGeo yk_lut_geo(int sx, int sy, int w) {
 // per tile slot of a pass: what the compaction needs
 struct LutSlot { uint16_t type; uint8_t box[6]; uint8_t mode; uint8_t pixels; uint8_t found; uint8_t pad; };      // 12 bytes
 
-// ---- one workgroup (128 threads) per tile ---------------------------------------------------------------------------------------
-// thread t = the t-th pixel of the tile in the order computeValues3D walks it (left 8 columns first for 16-wide tiles, :5856-5859)
+// ---- one workgroup per tile: 128 threads for the 128-pixel shapes, one wave for the others -------------------------------------------
+// Thread t holds pixel t & (nPix - 1) in the order computeValues3D walks the tile (left 8 columns first for 16-wide tiles, :5856-5859); with
+// fewer than 64 pixels the wave holds the tile 64 / nPix times and every copy evaluates its own share of the patterns.
 __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
-                                                            int w, int h, LutGeo g, const YkLutBank* __restrict__ bank, uint32_t* __restrict__ covCh32, size_t covStride,
+                                                            int w, int h, LutGeo g, const YkLutBank bank, uint32_t* __restrict__ covCh32, size_t covStride,
                                                             int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap) {
-    __shared__ int s_i64[128];                                              // normalised 6-bit coordinates x | y << 6 | z << 12, -1 = masked pixel
-    __shared__ int s_box[6], s_n;
-    // sized by the bank at launch (a 64-pattern bank needs 19 KB, the usual handful 2 KB: four more workgroups per CU)
-    extern __shared__ int s_dyn[];
-    const int nPatS = bank->nPat;
-    int* const s_sum = s_dyn;                                               // [nPat][48]
-    int* const s_mode = s_sum + nPatS * 48;                                 // [nPat]
-    int (*const s_acc)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPatS);   // [nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
-    int (*const s_part0)[8] = s_acc + nPatS;                                // the same per wave
-    int (*const s_part1)[8] = s_part0 + nPatS;
+    __shared__ __attribute__((aligned(16))) int s_cell[128];               // normalised 6-bit coordinates x | y << 8 | z << 16 of the live pixels, compacted
+    __shared__ int s_box[6], s_n, s_csq, s_boxw[2][8];                     // s_boxw: per wave, packed minima of the box + live pixels
     __shared__ int s_best[4];                                               // pattern, orientation, bit mode, found
+    // sized by the bank at launch (a 64-pattern bank needs 17 KB, the usual handful 2 KB)
+    extern __shared__ int s_dyn[];
+    const int nPat = bank.nPat;
+    int* const s_sum = s_dyn;                                               // [nPat][48]: the scores
+    int* const s_mode = s_sum + nPat * 48;                                  // [nPat]: first orientation with the smallest score
+    int (*const s_part)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPat);   // [2 waves][nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
     const int t = threadIdx.x, NT = blockDim.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;      // NT = 128, or 64 for tiles of at most 64 pixels
     const uint32_t pos = blockIdx.x;
     const uint32_t blk = pos / (uint32_t)g.bitCount, tt = pos % (uint32_t)g.bitCount;
     const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
     const int y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(tt / (uint32_t)g.tilesPerRow) * TY;
     if (x0 + TX > w || y0 + TY > h) { if (t == 0) slots[pos].found = 0; return; }             // partial tiles are never tried (:6304, :6311)
-    const int nPat = bank->nPat;
-    if (t < 6) s_box[t] = t < 3 ? 9999 : -1;
-    if (t == 0) s_n = 0;
-    __syncthreads();
+    if (t == 0) s_csq = 0;
     // buildBBox3D (:132-193): a pixel is out when all three planes already cover it; the box spans the others
-    int px = 0, py = 0; bool live = false; int v[3] = { 0, 0, 0 };
-    if (t < nPix) {
-        if (TX == 16) { px = (t & 7) + ((t / (8 * TY)) << 3); py = (t % (8 * TY)) >> 3; } else { px = t % TX; py = t / TX; }
+    const int tp = t & (nPix - 1);                                          // the thread's pixel; the first nPix threads are the tile, the others copies
+    const int copy = t / nPix, nCopies = NT / nPix;
+    int v[3] = { 0, 0, 0 };
+    bool liveP;
+    {
+        int px, py;
+        if (TX == 16) { px = (tp & 7) + ((tp / (8 * TY)) << 3); py = (tp % (8 * TY)) >> 3; } else { px = tp % TX; py = tp / TX; }
         const int gx = x0 + px, gy = y0 + py;
         const size_t mt = (size_t)(gy >> 4) * mtW + (gx >> 4);
         const int cbit = ((gy >> 2) & 3) * 4 + ((gx >> 2) & 3);
         const uint16_t* cov = reinterpret_cast<const uint16_t*>(covCh32);
-        live = !(((cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) >> cbit) & 1);
-        if (live) {
-            const size_t pi = (size_t)gy * strideElems + gx;
-            v[0] = pR[pi]; v[1] = pG[pi]; v[2] = pB[pi];
+        liveP = !(((cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) >> cbit) & 1);
+        if (liveP) { const size_t pi = (size_t)gy * strideElems + gx; v[0] = pR[pi]; v[1] = pG[pi]; v[2] = pB[pi]; }
+    }
+    const bool live = liveP && t < nPix;
+    const unsigned long long bal = __ballot(live);
+    {   // the box through wave reductions on packed 16-bit minima (max = 255 - min of 255 - v): the first version's LDS atomics on seven shared
+        // words were serialised lane by lane, 2.3 of a pass's 8 ms at 8192^2
+        y_us2 a = { (unsigned short)(live ? v[0] : 0xFFFF), (unsigned short)(live ? v[1] : 0xFFFF) };
+        y_us2 b = { (unsigned short)(live ? v[2] : 0xFFFF), (unsigned short)(live ? 255 - v[0] : 0xFFFF) };
+        y_us2 c = { (unsigned short)(live ? 255 - v[1] : 0xFFFF), (unsigned short)(live ? 255 - v[2] : 0xFFFF) };
 #pragma unroll
-            for (int c = 0; c < 3; c++) { atomicMin(&s_box[c], v[c]); atomicMax(&s_box[3 + c], v[c]); }
-            atomicAdd(&s_n, 1);
+        for (int off = 32; off >= 1; off >>= 1) {
+            a = __builtin_elementwise_min(a, yk_us2_from(__shfl_xor((int)yk_us2_bits(a), off)));
+            b = __builtin_elementwise_min(b, yk_us2_from(__shfl_xor((int)yk_us2_bits(b), off)));
+            c = __builtin_elementwise_min(c, yk_us2_from(__shfl_xor((int)yk_us2_bits(c), off)));
         }
+        if ((t & 63) == 0) {
+            int* o = s_boxw[t >> 6];
+            o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = __popcll(bal);
+        }
+    }
+    __syncthreads();
+    if (t < 7) {                                                            // fold the two waves' halves; empty = {9999 x3, -1 x3} as the reference leaves it
+        const int m0 = s_boxw[0][t], m1 = NT > 64 ? s_boxw[1][t] : (t == 6 ? 0 : 0xFFFF);
+        if (t == 6) s_n = m0 + m1;
+        else { const int m = min(m0, m1); s_box[t] = t < 3 ? (m == 0xFFFF ? 9999 : m) : (m == 0xFFFF ? -1 : 255 - m); }
     }
     __syncthreads();
     const int pixels = s_n;
@@ -164,46 +212,84 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     const bool accept = pixels != 0 && (((d[0] == 0) && d[1] != 0 && d[2] != 0) || ((d[1] == 0) && d[0] != 0 && d[2] != 0) || ((d[2] == 0) && d[0] != 0 && d[1] != 0) ||
                                         (d[0] != 0 && d[1] != 0 && d[2] != 0));                 // :6322-6326
     if (!accept || nPat == 0) { if (t == 0) slots[pos].found = 0; return; }
+#if YK_LUT_ABLATE == 3
+    if (t == 0) slots[pos].found = 0;
+    return;
+#endif
+    const int rank = __popcll(bal & ((1ULL << (t & 63)) - 1ULL)) + (t >= 64 ? s_boxw[0][6] : 0);  // position among the live pixels (thread order = the reference's walk)
     {   // coordinates for the scoring (:6389-6405): (int)(((v - lo) * ((1 << 20) / d)) / 2^20 * 63) in float
-        int cell = -1;
+        int csq = 0;
         if (live) {
             int q[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { const int n = d[c] ? (1 << 20) / d[c] : 0; const float f = __fdiv_rn((float)((v[c] - lo[c]) * n), 1048576.0f); q[c] = (int)__fmul_rn(f, 63.0f); }
-            cell = q[0] | (q[1] << 6) | (q[2] << 12);
+            s_cell[rank] = q[0] | (q[1] << 8) | (q[2] << 16);
+            csq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
         }
-        s_i64[t] = cell;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) csq += __shfl_xor(csq, off);
+        if ((t & 63) == 0 && csq) atomicAdd(&s_csq, csq);
     }
     __syncthreads();
-    // EvaluatePoint3D: sum of the distance field over the tile's pixels for every (pattern, orientation).  Threads 0..95 = two patterns x 48
-    // orientations per round; for one pixel the 48 lanes of a pattern read 96 contiguous bytes of its orientation-minor table.
-    const int perRound = NT >= 96 ? 2 : 1;
-    for (int k0 = 0; k0 < nPat; k0 += perRound) {
-        const int k = k0 + t / 48, m = t % 48;
-        if (t < 48 * perRound && k < nPat) {
-            const uint16_t* __restrict__ orient = bank->orient[k];
-            // branch-free and eight pixels at a time: the loads of a thread are independent, a loop of dependent-latency round trips (one
-            // load per iteration behind a test) was the whole cost of this kernel; s_i64 holds -1 beyond the tile's pixels
-            int sum = 0;
-            for (int p0 = 0; p0 < nPix; p0 += 8) {
-                int cell[8]; uint32_t d8[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) cell[j] = s_i64[p0 + j];
-#pragma unroll
-                for (int j = 0; j < 8; j++) d8[j] = orient[(size_t)max(cell[j], 0) * 48 + m];
-#pragma unroll
-                for (int j = 0; j < 8; j++) sum += cell[j] >= 0 ? (int)d8[j] : 0;
+    // EvaluatePoint3D: sum of the distance field over the tile's pixels for every (pattern, orientation); lane = one (pattern, orientation) pair
+    // with its eight transformed points in registers (the next round's are loaded under this round's arithmetic), the pixels come as LDS
+    // broadcasts: 8 dot products + 4 min3 + 1 add per pixel and lane.
+    const int nPairs = nPat * 48;
+    {
+        const int csqAll = s_csq;
+        auto points = [&](const int pi, uint4 (&q)[4]) {
+            const uint4* __restrict__ pt = reinterpret_cast<const uint4*>(bank.ptab + (size_t)min(pi, nPairs - 1) * 8);
+            q[0] = pt[0]; q[1] = pt[1]; q[2] = pt[2]; q[3] = pt[3];
+        };
+        uint4 q[4];
+        points(t, q);
+        for (int pi0 = t & ~63; pi0 < nPairs; pi0 += NT) {                  // wave-uniform bound
+            const int pi = pi0 + (t & 63);
+            uint4 qn[4];
+            const bool more = pi0 + NT < nPairs;
+            if (more) points(pi + NT, qn);
+            auto nearest = [&](const int a) {
+                const int d0 = yk_dot4(a, (int)q[0].x, (int)q[0].y), d1 = yk_dot4(a, (int)q[0].z, (int)q[0].w);
+                const int d2 = yk_dot4(a, (int)q[1].x, (int)q[1].y), d3 = yk_dot4(a, (int)q[1].z, (int)q[1].w);
+                const int d4 = yk_dot4(a, (int)q[2].x, (int)q[2].y), d5 = yk_dot4(a, (int)q[2].z, (int)q[2].w);
+                const int d6 = yk_dot4(a, (int)q[3].x, (int)q[3].y), d7 = yk_dot4(a, (int)q[3].z, (int)q[3].w);
+                return min(min(min(d0, d1), min(d2, d3)), min(min(d4, d5), min(d6, d7)));
+            };
+            int sum = 0, p0 = 0;
+#if YK_LUT_ABLATE == 1
+            p0 = pixels;
+#endif
+            for (; p0 + 4 <= pixels; p0 += 4) {
+                const int4 a = *reinterpret_cast<const int4*>(&s_cell[p0]);
+                sum += nearest(a.x) + nearest(a.y) + nearest(a.z) + nearest(a.w);
             }
-            s_sum[k * 48 + m] = sum;
+            for (; p0 < pixels; p0++) sum += nearest(s_cell[p0]);
+            if (pi < nPairs) s_sum[pi] = sum + csqAll;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) q[i] = qn[i];
+            }
         }
     }
     __syncthreads();
-    // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float
-    for (int k = t; k < nPat; k += NT) {
-        int res = -1; float minScore = 999999999.0f;
+#if YK_LUT_ABLATE == 4
+    if (t == 0) slots[pos].found = s_sum[0] == 12345;
+    return;
+#endif
+    // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float.  A wave per pattern: the quotients are not negative, so
+    // their bit patterns order like the values; the winner is the first lane that holds the wave's minimum.
+    {
         const float den = __fmul_rn((float)pixels, 1024.0f);
-        for (int f = 0; f < 48; f++) { const float avg = __fdiv_rn((float)s_sum[k * 48 + f], den); if (avg < minScore) { minScore = avg; res = f; } }
-        s_mode[k] = res;
+        const int l = t & 63;
+        for (int k = t >> 6; k < nPat; k += NT >> 6) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (l < 48) key = __float_as_uint(__fdiv_rn((float)s_sum[k * 48 + l], den));
+            uint32_t mn = key;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+            const unsigned long long first = __ballot(key == mn);
+            if (l == 0) s_mode[k] = __ffsll((long long)first) - 1;
+        }
     }
     __syncthreads();
     // computeValues3D for every pattern at its best orientation: per pixel the entry at 6 / 5 / 4 / 3 bits and its worst channel error.
@@ -212,71 +298,84 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     float relp[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        float rel = live ? (float)(v[c] - lo[c]) : 0.0f;
+        float rel = liveP ? (float)(v[c] - lo[c]) : 0.0f;
         if (d[c]) rel = __fdiv_rn(rel, (float)d[c]);
         relp[c] = __fmul_rn(rel, 63.0f);
     }
-    auto entry = [&](int k, int mode, int depth /*0 = 6 bit*/, int& idx, int (&col)[3]) {
+    // the cell of this pixel in pattern space under orientation `mode`, and the colour of entry idx at one depth
+    auto cellOf = [&](int mode) {
         int m[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) m[c] = ((mode >> c) & 1) ? (int)__fsub_rn(63.0f, relp[c]) : (int)relp[c];
         yk_lut_swap(mode >> 3, m[0], m[1], m[2]);
-        idx = bank->pos[k][(size_t)depth * LUT_CUBE + (m[0] + m[1] * 64 + (m[2] << 12))];
-        const int16_t* __restrict__ fac = bank->fac[k] + depth * 3 * 64;
-        int co[3] = { fac[idx], fac[64 + idx], fac[128 + idx] };
+        return m[0] + m[1] * 64 + (m[2] << 12);
+    };
+    auto colour = [&](int k, int mode, int depth /*0 = 6 bit*/, int idx, int (&col)[3]) {
+        const short4 f = bank.fac[(k * 4 + depth) * 64 + idx];
+        int co[3] = { f.x, f.y, f.z };
 #pragma unroll
         for (int c = 0; c < 3; c++) if ((mode >> c) & 1) co[c] = LUT_FACTOR - co[c];
         yk_lut_swap(mode >> 3, co[0], co[1], co[2]);
 #pragma unroll
         for (int c = 0; c < 3; c++) col[c] = lo[c] + (co[c] * d[c]) / LUT_FACTOR;
     };
-    // per pattern: the four depths' worst-channel errors of this pixel, summed over the tile with wave reductions (two 16-bit sums per
-    // shuffle word: a tile holds at most 128 pixels of error <= 255) and ballots for the ">5" counts; LDS atomics on eight shared words
-    // per pattern serialised all 64 lanes of a wave and were the larger half of this kernel's time
+    // per pattern: the four depths' worst-channel errors of this pixel, summed over the tile's lanes with shuffles that stay inside the copy
+    // (two 16-bit sums per word: a tile holds at most 128 pixels of error <= 255) and ballots for the ">5" counts; LDS atomics on eight
+    // shared words per pattern serialised all 64 lanes of a wave and were the larger half of the first version's time
     {
-        const int wv = t >> 6;
+        const int wv = t >> 6, seg = min(nPix, 64);
+        const unsigned long long segMask = seg == 64 ? ~0ULL : (((1ULL << seg) - 1ULL) << ((t & 63) - tp));
         auto evalPattern = [&](const int k, int (&w4)[4]) {
             const int mode = s_mode[k];
+            const uint32_t entries = bank.pos[(size_t)k * LUT_CUBE + cellOf(mode)];
 #pragma unroll
             for (int depth = 0; depth < 4; depth++) {
-                int idx, col[3];
-                entry(k, mode, depth, idx, col);
-                w4[depth] = live ? max(max(abs(col[0] - v[0]), abs(col[1] - v[1])), abs(col[2] - v[2])) : 0;
+                int col[3];
+                colour(k, mode, depth, (int)((entries >> (8 * depth)) & 255u), col);
+                w4[depth] = liveP ? max(max(abs(col[0] - v[0]), abs(col[1] - v[1])), abs(col[2] - v[2])) : 0;
             }
         };
         auto reducePattern = [&](const int k, const int (&w4)[4]) {
             int s01 = w4[0] | (w4[1] << 16), s23 = w4[2] | (w4[3] << 16);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { s01 += __shfl_xor(s01, off); s23 += __shfl_xor(s23, off); }
-            const int c0 = __popcll(__ballot(w4[0] > 5)), c1 = __popcll(__ballot(w4[1] > 5)), c2 = __popcll(__ballot(w4[2] > 5)), c3 = __popcll(__ballot(w4[3] > 5));
-            if ((t & 63) == 0) {
-                int* a = (wv ? s_part1 : s_part0)[k];
+            for (int off = seg >> 1; off >= 1; off >>= 1) { s01 += __shfl_xor(s01, off); s23 += __shfl_xor(s23, off); }
+            const int c0 = __popcll(__ballot(w4[0] > 5) & segMask), c1 = __popcll(__ballot(w4[1] > 5) & segMask);
+            const int c2 = __popcll(__ballot(w4[2] > 5) & segMask), c3 = __popcll(__ballot(w4[3] > 5) & segMask);
+            if ((tp & 63) == 0 && k < nPat) {
+                int* a = s_part[wv * nPat + k];
                 a[0] = s01 & 0xFFFF; a[1] = s01 >> 16; a[2] = s23 & 0xFFFF; a[3] = s23 >> 16; a[4] = c0; a[5] = c1; a[6] = c2; a[7] = c3;
             }
         };
-        // two patterns per round: their eight look-up chains (cell -> entry -> three factors) are in flight together.  Lanes without a pixel
-        // run the same loads on a harmless cell (every lane of a wave takes part in the reductions) and contribute 0.
-        for (int k = 0; k < nPat; k += 2) {
+        // two patterns per copy and round: their eight look-up chains (cell -> entry -> three factors) are in flight together.  Lanes without a
+        // pixel and copies without a pattern run the same loads on a harmless cell / the last pattern (every lane of a wave takes part in the
+        // reductions) and contribute nothing.
+        for (int kk = 0; kk < (YK_LUT_ABLATE == 2 ? 0 : nPat); kk += 2 * nCopies) {
+            const int ka = kk + copy, kb = ka + nCopies;
+            const bool second = kk + nCopies < nPat;
             int wa[4], wb[4] = { 0, 0, 0, 0 };
-            evalPattern(k, wa);
-            if (k + 1 < nPat) evalPattern(k + 1, wb);
-            reducePattern(k, wa);
-            if (k + 1 < nPat) reducePattern(k + 1, wb);
+            evalPattern(min(ka, nPat - 1), wa);
+            if (second) evalPattern(min(kb, nPat - 1), wb);
+            reducePattern(ka, wa);
+            if (second) reducePattern(kb, wb);
         }
     }
     __syncthreads();
-    for (int i = t; i < nPat * 8; i += NT) s_acc[i >> 3][i & 7] = s_part0[i >> 3][i & 7] + (NT > 64 ? s_part1[i >> 3][i & 7] : 0);
-    __syncthreads();
+#if YK_LUT_ABLATE == 5
+    if (t == 0) slots[pos].found = s_part[0][4] == 12345;
+    return;
+#endif
     if (t == 0) {
         // :6066-6069 (lowest depth that is not rejected, a depth is rejected when more than 3 pixels are off by more than 5) and the choice
         // among patterns :6486 (smallest summed error, the LATER pattern on a tie)
         int found = 0, bestK = -1, bestMode = 4, diffSum = (int)99999999999LL;
         for (int k = 0; k < nPat; k++) {
+            int acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] = s_part[k][i] + (NT > 64 ? s_part[nPat + k][i] : 0);
             int res = 4, diff = 0;
-            if (s_acc[k][4] <= 3) { diff = s_acc[k][0]; res = 3; }
-            if (s_acc[k][5] <= 3) { diff = s_acc[k][1]; res = 2; }
-            if (s_acc[k][6] <= 3) { diff = s_acc[k][2]; res = 1; }
-            if (s_acc[k][7] <= 3) { diff = s_acc[k][3]; res = 0; }
+            if (acc[4] <= 3) { diff = acc[0]; res = 3; }
+            if (acc[5] <= 3) { diff = acc[1]; res = 2; }
+            if (acc[6] <= 3) { diff = acc[2]; res = 1; }
+            if (acc[7] <= 3) { diff = acc[3]; res = 0; }
             if (res != 4 && diff <= diffSum) { found = 1; bestK = k; bestMode = res; diffSum = diff; }
         }
         s_best[0] = bestK; s_best[1] = found ? s_mode[bestK] : 0; s_best[2] = bestMode; s_best[3] = found;
@@ -289,16 +388,10 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     }
     __syncthreads();
     if (!s_best[3]) return;
-    // the winner's indices in stream order: rank of the pixel among the live ones (thread order = the reference's walk)
-    const unsigned long long bal = __ballot(live);
-    __shared__ int s_w0;
-    if (t == 0) s_w0 = __popcll(bal);
-    __syncthreads();
+    // the winner's indices in stream order
     if (live) {
-        const int rank = __popcll(bal & ((1ULL << (t & 63)) - 1ULL)) + (t >= 64 ? s_w0 : 0);      // s_w0: live pixels of the first wave
-        int idx, col[3];
-        entry(s_best[0], s_best[1], 3 - s_best[2], idx, col);
-        slotIdx[(size_t)pos * nPix + rank] = (uint8_t)idx;
+        const uint32_t entries = bank.pos[(size_t)s_best[0] * LUT_CUBE + cellOf(s_best[1])];
+        slotIdx[(size_t)pos * nPix + rank] = (uint8_t)(entries >> (8 * (3 - s_best[2])));
     }
     // the tile leaves the pool: all three planes, every cell of the tile (:6760-6766); cells of other tiles share words -> atomics
     if (t < (TX >> 2) * (TY >> 2)) {
@@ -359,8 +452,8 @@ __global__ __launch_bounds__(1024) void yk_lut_emit_kernel(const LutSlot* __rest
 static void yk_lut_release(yk_ctx* c) {
     YkLutState* S = c->lut; if (!S) return;
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    for (int k = 0; k < S->nPat; k++) { F(S->pat[k].dist); F(S->pat[k].orient); F(S->pat[k].pos); F(S->pat[k].fac); }
-    F(S->bankDev); F(S->tileType); F(S->color);
+    for (int k = 0; k < S->nPat; k++) F(S->pat[k].dist);
+    F(S->ptab); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->tileType); F(S->color);
     for (auto& p : S->idx) F(p);
     for (auto& p : S->map) F(p);
     delete S; c->lut = nullptr;
@@ -383,12 +476,11 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     if (count < 1 || count > 64) return yk_fail(c, YK_ERR_BAD_ARG, "a pattern holds 1..64 points");
     for (int n = 0; n < count; n++) if (r[n] > 63 || g[n] > 63 || b[n] > 63) return yk_fail(c, YK_ERR_BAD_ARG, "pattern coordinates are 6 bits");
     YK_HIP(c, hipSetDevice(c->device));
-    if (!c->lut) {
-        c->lut = new YkLutState();
-        uint8_t perm[48]; yk_lut_perm_table(perm);
-        YK_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_lutPerm), perm, sizeof perm));
-    }
+    if (!c->lut) c->lut = new YkLutState();
     YkLutState* S = c->lut;
+    if (!S->ptab) YK_HIP(c, hipMalloc(&S->ptab, (size_t)LUT_MAXPAT * 48 * 8 * sizeof(uint2)));
+    if (!S->posAll) YK_HIP(c, hipMalloc(&S->posAll, (size_t)LUT_MAXPAT * LUT_CUBE * sizeof(uint32_t)));
+    if (!S->facAll) YK_HIP(c, hipMalloc(&S->facAll, (size_t)LUT_MAXPAT * 4 * 64 * sizeof(short4)));
     if (S->nPat >= LUT_MAXPAT) return yk_fail(c, YK_ERR_RANGE, "LUT 3D more than 64 entries");     // :7912
     uint8_t pts[64 * 3];
     for (int n = 0; n < count; n++) { pts[n * 3] = r[n]; pts[n * 3 + 1] = g[n]; pts[n * 3 + 2] = b[n]; }
@@ -405,25 +497,24 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     YkLutPattern& P = S->pat[S->nPat];
     P.count = count;
     YK_HIP(c, hipMalloc(&P.dist, LUT_CUBE * sizeof(uint16_t)));
-    YK_HIP(c, hipMalloc(&P.orient, (size_t)LUT_CUBE * 48 * sizeof(uint16_t)));
-    YK_HIP(c, hipMalloc(&P.pos, 4 * LUT_CUBE));
-    YK_HIP(c, hipMalloc(&P.fac, sizeof fac));
+    P.pos = S->posAll + (size_t)S->nPat * LUT_CUBE;
+    P.fac = S->facAll + (size_t)S->nPat * 4 * 64;
+    short4 fac4[4][64];
+    for (int step = 0; step < 4; step++)
+        for (int e = 0; e < 64; e++) fac4[step][e] = make_short4(fac[step][0][e], fac[step][1][e], fac[step][2][e], 0);
     uint8_t* dPts = nullptr;
     YK_HIP(c, hipMalloc(&dPts, 64 * 3));
     YK_HIP(c, hipMemcpyAsync(dPts, pts, (size_t)count * 3, hipMemcpyHostToDevice, c->stream));
-    YK_HIP(c, hipMemcpyAsync(P.fac, fac, sizeof fac, hipMemcpyHostToDevice, c->stream));
+    YK_HIP(c, hipMemcpyAsync(P.fac, fac4, sizeof fac4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(yk_lut_build_kernel, dim3(LUT_CUBE / 256), dim3(256), 0, c->stream, dPts, count, P.dist, P.pos);
-    hipLaunchKernelGGL(yk_lut_orient_kernel, dim3((unsigned)(((size_t)LUT_CUBE * 48 + 255) / 256)), dim3(256), 0, c->stream, P.dist, P.orient);
+    uint2 ptab[48 * 8];
+    yk_lut_point_table(pts, count, ptab);
+    YK_HIP(c, hipMemcpyAsync(S->ptab + (size_t)S->nPat * 48 * 8, ptab, sizeof ptab, hipMemcpyHostToDevice, c->stream));
     YK_HIP(c, hipGetLastError());
     YK_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(dPts);
     if (index) *index = S->nPat;
     S->nPat++;
-    YkLutBank bank = {};
-    for (int k = 0; k < S->nPat; k++) { bank.orient[k] = S->pat[k].orient; bank.pos[k] = S->pat[k].pos; bank.fac[k] = S->pat[k].fac; }
-    bank.nPat = S->nPat;
-    if (!S->bankDev) YK_HIP(c, hipMalloc(&S->bankDev, sizeof(YkLutBank)));
-    YK_HIP(c, hipMemcpy(S->bankDev, &bank, sizeof bank, hipMemcpyHostToDevice));
     return YK_OK;
 }
 
@@ -431,9 +522,19 @@ int yk_lut_pattern_tables(yk_ctx* c, int pattern, int16_t* factors /*4*3*64*/, u
     if (!c || !c->lut || pattern < 0 || pattern >= c->lut->nPat) return YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));
     const YkLutPattern& P = c->lut->pat[pattern];
-    if (factors) YK_HIP(c, hipMemcpy(factors, P.fac, 4 * 3 * 64 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (factors) {                                                             // exported in the reference's layout [depth][channel][entry]
+        short4 fac4[4][64];
+        YK_HIP(c, hipMemcpy(fac4, P.fac, sizeof fac4, hipMemcpyDeviceToHost));
+        for (int step = 0; step < 4; step++)
+            for (int e = 0; e < 64; e++) { factors[(step * 3 + 0) * 64 + e] = fac4[step][e].x; factors[(step * 3 + 1) * 64 + e] = fac4[step][e].y; factors[(step * 3 + 2) * 64 + e] = fac4[step][e].z; }
+    }
     if (distanceField) YK_HIP(c, hipMemcpy(distanceField, P.dist, LUT_CUBE * sizeof(uint16_t), hipMemcpyDeviceToHost));
-    if (positions) YK_HIP(c, hipMemcpy(positions, P.pos, 4 * LUT_CUBE, hipMemcpyDeviceToHost));
+    if (positions) {                                                           // [depth][cell]
+        std::vector<uint32_t> e(LUT_CUBE);
+        YK_HIP(c, hipMemcpy(e.data(), P.pos, LUT_CUBE * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int step = 0; step < 4; step++)
+            for (int i = 0; i < LUT_CUBE; i++) positions[(size_t)step * LUT_CUBE + i] = (uint8_t)(e[i] >> (8 * step));
+    }
     return YK_OK;
 }
 
@@ -445,19 +546,29 @@ int yk_lut_start(yk_ctx* c) {
     YK_HIP(c, hipSetDevice(c->device));
     YkLutState* S = c->lut;
     const int w = c->fullW, h = c->h;
-    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(S->tileType); F(S->color); for (auto& p : S->idx) F(p); for (auto& p : S->map) F(p);
-    S->capTiles = (size_t)(w / 4) * (h / 4) + 16; S->capPix = (size_t)w * h + 128;
-    YK_HIP(c, hipMalloc(&S->tileType, S->capTiles * 2));
-    YK_HIP(c, hipMalloc(&S->color, S->capTiles * 6));
-    for (auto& p : S->idx) YK_HIP(c, hipMalloc(&p, S->capPix));
     static const int sz[6][2] = { {4,3}, {3,4}, {3,3}, {3,2}, {2,3}, {2,2} };
-    for (int k = 0; k < 6; k++) {
-        const LutGeo g = yk_lut_geo(sz[k][0], sz[k][1], w);
-        S->mapBytes[k] = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount;       // BitmapSwizzleMapSize (:7310): a bit count used as the byte size
-        YK_HIP(c, hipMalloc(&S->map[k], S->mapBytes[k] + 16));
-        YK_HIP(c, hipMemsetAsync(S->map[k], 0, S->mapBytes[k] + 16, c->stream));
+    const size_t capTiles = (size_t)(w / 4) * (h / 4) + 16, capPix = (size_t)w * h + 128;
+    if (w != S->capW || h != S->capH) {                      // a new image size: the streams, the maps and the per-pass scratch
+        auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        F(S->tileType); F(S->color); for (auto& p : S->idx) F(p); for (auto& p : S->map) F(p); F(S->slots); F(S->slotIdx); F(S->sums);
+        S->capTiles = S->capPix = 0; S->capW = S->capH = 0;
+        YK_HIP(c, hipMalloc(&S->tileType, capTiles * 2));
+        YK_HIP(c, hipMalloc(&S->color, capTiles * 6));
+        for (auto& p : S->idx) YK_HIP(c, hipMalloc(&p, capPix));
+        size_t maxSlots = 0;
+        for (int k = 0; k < 6; k++) {
+            const LutGeo g = yk_lut_geo(sz[k][0], sz[k][1], w);
+            S->mapBytes[k] = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount;       // BitmapSwizzleMapSize (:7310): a bit count used as the byte size
+            YK_HIP(c, hipMalloc(&S->map[k], S->mapBytes[k] + 16));
+            maxSlots = std::max(maxSlots, S->mapBytes[k]);                                    // = the pass's tile slots
+        }
+        YK_HIP(c, hipMalloc(&S->slots, maxSlots * sizeof(LutSlot)));
+        YK_HIP(c, hipMalloc(&S->slotIdx, (size_t)(w + 64) * (h + 64)));                      // slots x pixels per tile = whole swizzle blocks (64 x 64 at most), any shape
+        YK_HIP(c, hipMalloc(&S->sums, (5 * ((maxSlots + 1023) / 1024) + 16) * sizeof(uint32_t)));
+        S->capTiles = capTiles; S->capPix = capPix; S->capW = w; S->capH = h;
     }
+    for (int k = 0; k < 6; k++) YK_HIP(c, hipMemsetAsync(S->map[k], 0, S->mapBytes[k] + 16, c->stream));
     S->nType = S->nColor = 0; for (auto& n : S->nIdx) n = 0;
     { int rc = yk_pp_activate(c); if (rc) return rc; }                          // LUT tiles paint mapSmoothTile only, never smoothMap
     S->started = true;
@@ -474,13 +585,11 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     YkLutState* S = c->lut;
     const int w = c->fullW, h = c->h, nPix = (1 << shiftX) * (1 << shiftY);
     const size_t nSlots = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount, nb = (nSlots + 1023) / 1024;
-    LutSlot* slots = nullptr; uint8_t* slotIdx = nullptr; uint32_t* sums = nullptr;
-    YK_HIP(c, hipMalloc(&slots, nSlots * sizeof(LutSlot)));
-    YK_HIP(c, hipMalloc(&slotIdx, nSlots * nPix));
-    YK_HIP(c, hipMalloc(&sums, (5 * nb + 16) * sizeof(uint32_t)));
+    LutSlot* const slots = S->slots; uint8_t* const slotIdx = S->slotIdx; uint32_t* const sums = S->sums;    // yk_lut_start sized them
+    YkLutBank bank; bank.ptab = S->ptab; bank.pos = S->posAll; bank.fac = S->facAll; bank.nPat = S->nPat;
     { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 24) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
-                       S->bankDev, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
+    hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
+                       bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
     { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_lut_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, slots, nSlots, sums, nb);
     hipLaunchKernelGGL(yk_lut_scan_kernel, dim3(1), dim3(1024), 0, c->stream, sums, nb, sums + 5 * nb);
@@ -491,7 +600,6 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     uint32_t tot[5] = {};
     if (e == hipSuccess) e = hipMemcpyAsync(tot, sums + 5 * nb, sizeof tot, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(slots); (void)hipFree(slotIdx); (void)hipFree(sums);
     if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "3-D LUT search", e);
     S->nType += tot[0]; S->nColor += (size_t)tot[0] * 6;
     for (int m = 0; m < 4; m++) S->nIdx[m] += tot[1 + m];
