@@ -17,6 +17,8 @@
 // Not on the timed path of bench.py.
 #include "yk_common.h"
 #include "yk_device.h"
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 #define LUT_CUBE (64 * 64 * 64)
@@ -24,14 +26,19 @@
 #define LUT_MAXPAT 64
 
 struct YkLutPattern { uint16_t* dist; uint32_t* pos; short4* fac; int count; };      // device pointers
-// ptab[(pattern * 48 + orientation) * 8 + j] = the j-th point of the pattern's 3-bit subset as that orientation sees it (yk_lut_point_table)
+// ptab[pair * 8 + j] = the j-th point of a pattern's 3-bit subset as one orientation sees it (yk_lut_point_table).  Orientations of a pattern that
+// see the same SET of points score alike on every tile and the reference keeps the first of them (a strict `<`), so only the first of each
+// such group is a pair: pairs patStart[k] .. patStart[k + 1] - 1 belong to pattern k in the order of their orientations pairMode[pair] (a
+// colour ramp along the cube's diagonal has 4 distinct orientations, not 48).
 // pos[pattern * 64^3 + cell] = the cell's nearest entry at 6 | 5 << 8 | 4 << 16 | 3 << 24 bits (one gather serves the four depths: the gathers into
 // these 1 MB tables are what the search waits for); fac[(pattern * 4 + depth) * 64 + entry] = the entry's three factors (x, y, z, 0).  One allocation
 // per table for the whole bank, passed as kernel arguments: no pointer per pattern to fetch first.
-struct YkLutBank { const uint2* ptab; const uint32_t* pos; const short4* fac; int nPat; };
+struct YkLutBank { const uint2* ptab; const uint8_t* pairMode; const int* patStart; const uint32_t* pos; const short4* fac; int nPat, nPairs; };
 struct YkLutState {
     YkLutPattern pat[LUT_MAXPAT]; int nPat = 0;
-    uint2* ptab = nullptr;                  // [LUT_MAXPAT][48][8], 192 KB
+    uint2* ptab = nullptr;                  // [<= LUT_MAXPAT * 48 pairs][8], 192 KB
+    uint8_t* pairMode = nullptr; int* patStart = nullptr;
+    std::vector<uint2> hPtab; std::vector<uint8_t> hPairMode; std::vector<int> hPatStart = { 0 };      // host copies, grown by every yk_lut_load_pattern
     uint32_t* posAll = nullptr;             // [LUT_MAXPAT][64^3], 64 MB (allocated with the first pattern)
     short4* facAll = nullptr;               // [LUT_MAXPAT][4][64]
     bool started = false;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     // sized by the bank at launch (a 64-pattern bank needs 17 KB, the usual handful 2 KB)
     extern __shared__ int s_dyn[];
     const int nPat = bank.nPat;
-    int* const s_sum = s_dyn;                                               // [nPat][48]: the scores
+    int* const s_sum = s_dyn;                                               // [nPairs <= nPat * 48]: the scores
     int* const s_mode = s_sum + nPat * 48;                                  // [nPat]: first orientation with the smallest score
     int (*const s_part)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPat);   // [2 waves][nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
     const int t = threadIdx.x, NT = blockDim.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;      // NT = 128, or 64 for tiles of at most 64 pixels
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     // EvaluatePoint3D: sum of the distance field over the tile's pixels for every (pattern, orientation); lane = one (pattern, orientation) pair
     // with its eight transformed points in registers (the next round's are loaded under this round's arithmetic), the pixels come as LDS
     // broadcasts: 8 dot products + 4 min3 + 1 add per pixel and lane.
-    const int nPairs = nPat * 48;
+    const int nPairs = bank.nPairs;
     {
         const int csqAll = s_csq;
         auto points = [&](const int pi, uint4 (&q)[4]) {
@@ -282,13 +289,14 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         const float den = __fmul_rn((float)pixels, 1024.0f);
         const int l = t & 63;
         for (int k = t >> 6; k < nPat; k += NT >> 6) {
+            const int first0 = bank.patStart[k], cnt = bank.patStart[k + 1] - first0;
             uint32_t key = 0xFFFFFFFFu;
-            if (l < 48) key = __float_as_uint(__fdiv_rn((float)s_sum[k * 48 + l], den));
+            if (l < cnt) key = __float_as_uint(__fdiv_rn((float)s_sum[first0 + l], den));
             uint32_t mn = key;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
             const unsigned long long first = __ballot(key == mn);
-            if (l == 0) s_mode[k] = __ffsll((long long)first) - 1;
+            if (l == 0) s_mode[k] = bank.pairMode[first0 + __ffsll((long long)first) - 1];
         }
     }
     __syncthreads();
@@ -453,7 +461,7 @@ static void yk_lut_release(yk_ctx* c) {
     YkLutState* S = c->lut; if (!S) return;
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int k = 0; k < S->nPat; k++) F(S->pat[k].dist);
-    F(S->ptab); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->tileType); F(S->color);
+    F(S->ptab); F(S->pairMode); F(S->patStart); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->tileType); F(S->color);
     for (auto& p : S->idx) F(p);
     for (auto& p : S->map) F(p);
     delete S; c->lut = nullptr;
@@ -479,6 +487,8 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     if (!c->lut) c->lut = new YkLutState();
     YkLutState* S = c->lut;
     if (!S->ptab) YK_HIP(c, hipMalloc(&S->ptab, (size_t)LUT_MAXPAT * 48 * 8 * sizeof(uint2)));
+    if (!S->pairMode) YK_HIP(c, hipMalloc(&S->pairMode, (size_t)LUT_MAXPAT * 48));
+    if (!S->patStart) YK_HIP(c, hipMalloc(&S->patStart, (LUT_MAXPAT + 1) * sizeof(int)));
     if (!S->posAll) YK_HIP(c, hipMalloc(&S->posAll, (size_t)LUT_MAXPAT * LUT_CUBE * sizeof(uint32_t)));
     if (!S->facAll) YK_HIP(c, hipMalloc(&S->facAll, (size_t)LUT_MAXPAT * 4 * 64 * sizeof(short4)));
     if (S->nPat >= LUT_MAXPAT) return yk_fail(c, YK_ERR_RANGE, "LUT 3D more than 64 entries");     // :7912
@@ -507,9 +517,22 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     YK_HIP(c, hipMemcpyAsync(dPts, pts, (size_t)count * 3, hipMemcpyHostToDevice, c->stream));
     YK_HIP(c, hipMemcpyAsync(P.fac, fac4, sizeof fac4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(yk_lut_build_kernel, dim3(LUT_CUBE / 256), dim3(256), 0, c->stream, dPts, count, P.dist, P.pos);
-    uint2 ptab[48 * 8];
-    yk_lut_point_table(pts, count, ptab);
-    YK_HIP(c, hipMemcpyAsync(S->ptab + (size_t)S->nPat * 48 * 8, ptab, sizeof ptab, hipMemcpyHostToDevice, c->stream));
+    {
+        uint2 ptab[48 * 8];
+        yk_lut_point_table(pts, count, ptab);
+        const size_t firstPair = S->hPairMode.size();
+        for (int m = 0; m < 48; m++) {
+            uint2* e = ptab + m * 8;                                            // as a set: the order of the points does not matter to a minimum
+            std::sort(e, e + 8, [](const uint2& a, const uint2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+            bool seen = false;
+            for (size_t q = firstPair; q < S->hPairMode.size() && !seen; q++) seen = memcmp(&S->hPtab[q * 8], e, 8 * sizeof(uint2)) == 0;
+            if (!seen) { S->hPtab.insert(S->hPtab.end(), e, e + 8); S->hPairMode.push_back((uint8_t)m); }
+        }
+        S->hPatStart.push_back((int)S->hPairMode.size());
+        YK_HIP(c, hipMemcpyAsync(S->ptab, S->hPtab.data(), S->hPtab.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        YK_HIP(c, hipMemcpyAsync(S->pairMode, S->hPairMode.data(), S->hPairMode.size(), hipMemcpyHostToDevice, c->stream));
+        YK_HIP(c, hipMemcpyAsync(S->patStart, S->hPatStart.data(), S->hPatStart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     YK_HIP(c, hipGetLastError());
     YK_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(dPts);
@@ -586,7 +609,8 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     const int w = c->fullW, h = c->h, nPix = (1 << shiftX) * (1 << shiftY);
     const size_t nSlots = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount, nb = (nSlots + 1023) / 1024;
     LutSlot* const slots = S->slots; uint8_t* const slotIdx = S->slotIdx; uint32_t* const sums = S->sums;    // yk_lut_start sized them
-    YkLutBank bank; bank.ptab = S->ptab; bank.pos = S->posAll; bank.fac = S->facAll; bank.nPat = S->nPat;
+    YkLutBank bank; bank.ptab = S->ptab; bank.pairMode = S->pairMode; bank.patStart = S->patStart; bank.pos = S->posAll; bank.fac = S->facAll;
+    bank.nPat = S->nPat; bank.nPairs = (int)S->hPairMode.size();
     { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
     hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
                        bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
