@@ -28,8 +28,8 @@
 struct YkLutPattern { uint16_t* dist; uint32_t* pos; short4* fac; int count; };      // device pointers
 // ptab[pair * 8 + j] = the j-th point of a pattern's 3-bit subset as one orientation sees it (yk_lut_point_table).  Orientations of a pattern that
 // see the same SET of points score alike on every tile and the reference keeps the first of them (a strict `<`), so only the first of each
-// such group is a pair: pairs patStart[k] .. patStart[k + 1] - 1 belong to pattern k in the order of their orientations pairMode[pair] (a
-// colour ramp along the cube's diagonal has 4 distinct orientations, not 48).
+// such group is a pair: pairs patStart[k] .. patStart[k + 1] - 1 belong to pattern k in the order of their orientations pairMode[pair] (the
+// cumulative permutations reach at most 28 distinct orientations, a colour ramp along the cube's diagonal has 8).
 // pos[pattern * 64^3 + cell] = the cell's nearest entry at 6 | 5 << 8 | 4 << 16 | 3 << 24 bits (one gather serves the four depths: the gathers into
 // these 1 MB tables are what the search waits for); fac[(pattern * 4 + depth) * 64 + entry] = the entry's three factors (x, y, z, 0).  One allocation
 // per table for the whole bank, passed as kernel arguments: no pointer per pattern to fetch first.
