@@ -136,6 +136,9 @@ typedef unsigned short y_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t yk_us2_bits(y_us2 a) { return (uint32_t)a.x | ((uint32_t)a.y << 16); }
 __device__ __forceinline__ y_us2 yk_us2_from(int b) { y_us2 r = { (unsigned short)((uint32_t)b & 0xFFFFu), (unsigned short)((uint32_t)b >> 16) }; return r; }
 
+// |a - b| through the SAD unit (with a literal 0 addend the compiler expands __usad into min / max / sub)
+__device__ __forceinline__ uint32_t yk_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 struct LutGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow, mapId; };
 static LutGeo yk_lut_geo(int sx, int sy, int w) {
     LutGeo g; g.sx = sx; g.sy = sy;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         if (d[c]) rel = __fdiv_rn(rel, (float)d[c]);
         relp[c] = __fmul_rn(rel, 63.0f);
     }
-    // the cell of this pixel in pattern space under orientation `mode`, and the colour of entry idx at one depth
+    // the cell of this pixel in pattern space under orientation `mode`
     auto cellOf = [&](int mode) {
         int m[3];
 #pragma unroll
@@ -318,29 +321,31 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         yk_lut_swap(mode >> 3, m[0], m[1], m[2]);
         return m[0] + m[1] * 64 + (m[2] << 12);
     };
-    auto colour = [&](int k, int mode, int depth /*0 = 6 bit*/, int idx, int (&col)[3]) {
-        const short4 f = bank.fac[(k * 4 + depth) * 64 + idx];
-        int co[3] = { f.x, f.y, f.z };
-#pragma unroll
-        for (int c = 0; c < 3; c++) if ((mode >> c) & 1) co[c] = LUT_FACTOR - co[c];
-        yk_lut_swap(mode >> 3, co[0], co[1], co[2]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) col[c] = lo[c] + (co[c] * d[c]) / LUT_FACTOR;
-    };
     // per pattern: the four depths' worst-channel errors of this pixel, summed over the tile's lanes with shuffles that stay inside the copy
     // (two 16-bit sums per word: a tile holds at most 128 pixels of error <= 255) and ballots for the ">5" counts; LDS atomics on eight
     // shared words per pattern serialised all 64 lanes of a wave and were the larger half of the first version's time
     {
         const int wv = t >> 6, seg = min(nPix, 64);
         const unsigned long long segMask = seg == 64 ? ~0ULL : (((1ULL << seg) - 1ULL) << ((t & 63) - tp));
+        // The colour of an entry (:5889-5925) is lo + ((swap(flip(factors)) * d) / FACTOR) per channel and its error max |colour - v|.  Seen from the
+        // pattern's axes: axis a drives the channel the swap sends it to, so with W = v - lo and d permuted the other way ONCE per pattern, an axis
+        // costs mad (flip folded in: (F ? 128 - f : f) * d = f * (+-d) + (F ? 128 d : 0)), shift (all operands are >= 0), |x - W| per depth.
         auto evalPattern = [&](const int k, int (&w4)[4]) {
-            const int mode = s_mode[k];
+            const int mode = s_mode[k], sw = mode >> 3, back = sw == 3 ? 4 : (sw == 4 ? 3 : sw);     // the inverse of swap 3 is swap 4; the others are involutions
             const uint32_t entries = bank.pos[(size_t)k * LUT_CUBE + cellOf(mode)];
+            int W[3] = { v[0] - lo[0], v[1] - lo[1], v[2] - lo[2] }, D[3] = { d[0], d[1], d[2] };
+            yk_lut_swap(back, W[0], W[1], W[2]);
+            yk_lut_swap(back, D[0], D[1], D[2]);
+            int SD[3], BD[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const bool F = (mode >> a) & 1; SD[a] = F ? -D[a] : D[a]; BD[a] = F ? LUT_FACTOR * D[a] : 0; }
 #pragma unroll
             for (int depth = 0; depth < 4; depth++) {
-                int col[3];
-                colour(k, mode, depth, (int)((entries >> (8 * depth)) & 255u), col);
-                w4[depth] = liveP ? max(max(abs(col[0] - v[0]), abs(col[1] - v[1])), abs(col[2] - v[2])) : 0;
+                const short4 f = bank.fac[(k * 4 + depth) * 64 + (int)((entries >> (8 * depth)) & 255u)];
+                const uint32_t e0 = yk_absdiff((uint32_t)(f.x * SD[0] + BD[0]) >> 7, (uint32_t)W[0]);
+                const uint32_t e1 = yk_absdiff((uint32_t)(f.y * SD[1] + BD[1]) >> 7, (uint32_t)W[1]);
+                const uint32_t e2 = yk_absdiff((uint32_t)(f.z * SD[2] + BD[2]) >> 7, (uint32_t)W[2]);
+                w4[depth] = liveP ? (int)max(max(e0, e1), e2) : 0;
             }
         };
         auto reducePattern = [&](const int k, const int (&w4)[4]) {
