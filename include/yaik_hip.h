@@ -173,7 +173,7 @@ int    yk_coverage_plane(yk_ctx* c, int plane, uint16_t* hostOut, size_t capElem
  * mapSmoothTile, not smoothMap: yk_coverage_plane grows, yk_coverage does not).
  * yk_lut_load_pattern: one pattern of the bank = the contents of one 'Bank3D' .lut file (u8 count, r[], g[], b[], 6-bit values), at most 64
  * points (more make the reference overrun its tables, :7907-7917) and 64 patterns; *index = its number.  The bank belongs to the handle
- * and survives yk_set_image.  yk_lut_start allocates and clears the streams; yk_lut_search runs ONE tile shape (shiftX, shiftY) in
+ * and survives yk_set_image (the first pattern reserves the whole bank's tables in HBM: 64 MB of nearest-entry tables + 0.3 MB).  yk_lut_start allocates and clears the streams; yk_lut_search runs ONE tile shape (shiftX, shiftY) in
  * {(4,3),(3,4),(3,3),(3,2),(2,3),(2,2)} - the reference calls them in that order - and appends to the streams; *matched = tiles taken.
  * yk_lut_stream(which): 0 = corr3D_tileStreamTileType (u16: orientation | pattern << 6 | bitMode << 14, :6559), 1 = corr3D_colorStream
  * (box lo RGB, hi RGB per tile, before EndCorrelationSearch's CompressF :7494), 2..5 = corr3D_stream3Bit..6Bit (entry numbers, before the

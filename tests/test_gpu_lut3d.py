@@ -50,10 +50,22 @@ def test_pattern_tables_match_oracle(hip, oracle_built):
     hip.lut_clear()
 
 
+def test_bank_holds_64_patterns_and_refuses_the_65th(hip):
+    from yaik_amd._lib import YaikError
+    hip.lut_clear()
+    for p in random_bank(106, 64):
+        hip.lut_load(p)
+    with pytest.raises(YaikError):                                            # "LUT 3D more than 64 entries", EncoderContext.cpp:7912
+        hip.lut_load(random_bank(107, 1)[0])
+    hip.lut_clear()
+
+
 CASES = {
     "random_bank_a": lambda: (lut_image(128, 128, random_bank(101), seed=41), random_bank(101)),
     "random_bank_b": lambda: (lut_image(144, 112, random_bank(102, 7), seed=42), random_bank(102, 7)),
     "random_bank_c": lambda: (lut_image(256, 256, random_bank(104, 9), seed=43), random_bank(104, 9)),
+    # a full bank: 64 patterns (the LDS tables of the search are sized by the bank, the pair list is at its longest)
+    "full_bank_64": lambda: (lut_image(192, 160, random_bank(105, 64)[:6], seed=44), random_bank(105, 64)),
     "lut128": lambda: (lut_image(128, 128, seed=11), bank_patterns()),
     "lut200x136": lambda: (lut_image(200, 136, seed=5), bank_patterns()),
     "lut256_3patterns": lambda: (lut_image(256, 256, bank_patterns(3), seed=2), bank_patterns(3)),
