@@ -47,7 +47,7 @@ struct YkLutState {
     size_t nType = 0, nColor = 0, nIdx[4] = {}, mapBytes[6] = {};
     size_t capTiles = 0, capPix = 0; int capW = 0, capH = 0;
     // per-pass scratch, sized for the 4x4 pass and kept across passes and searches
-    struct LutSlot* slots = nullptr; uint8_t* slotIdx = nullptr; uint32_t* sums = nullptr;
+    struct LutSlot* slots = nullptr; uint8_t* slotIdx = nullptr; uint32_t* sums = nullptr; uint32_t* list = nullptr;
 };
 
 // the 48 orientations of EvaluatePoint3D: its axis swap of group n >> 3 is applied to the RUNNING x, y, z on every iteration of its loop
@@ -153,12 +153,44 @@ static LutGeo yk_lut_geo(int sx, int sy, int w) {
 // per tile slot of a pass: what the compaction needs
 struct LutSlot { uint16_t type; uint8_t box[6]; uint8_t mode; uint8_t pixels; uint8_t found; uint8_t pad; };      // 12 bytes
 
+// ---- the pass's candidate tiles: whole tiles with at least one pixel that some plane has not covered yet.  A tile of at most 16 x 8 pixels
+// lies inside one 16x16 macro-tile, so its cells are a mask of that macro-tile's coverage words.  The others get their "not found" here: the
+// search kernel is launched for the candidates only (on the bench frame half of the 4.2 M 4x4 slots have nothing left to code, and an empty
+// workgroup still costs its dispatch).  list[0] = count (zeroed by the caller), list[1..] in any order: the results go to per-slot records.
+__global__ __launch_bounds__(256) void yk_lut_list_kernel(const uint16_t* __restrict__ cov, size_t covStride, int mtW, LutGeo g, int w, int h, size_t nSlots,
+                                                          LutSlot* __restrict__ slots, uint32_t* __restrict__ list) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool cand = false;
+    if (pos < nSlots) {
+        const int TX = 1 << g.sx, TY = 1 << g.sy;
+        const uint32_t blk = (uint32_t)(pos / (uint32_t)g.bitCount), tt = (uint32_t)(pos % (uint32_t)g.bitCount);
+        const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
+        const int y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(tt / (uint32_t)g.tilesPerRow) * TY;
+        if (x0 + TX <= w && y0 + TY <= h) {                                  // partial tiles are never tried (:6304, :6311)
+            const size_t mt = (size_t)(y0 >> 4) * mtW + (x0 >> 4);
+            const uint32_t row = ((1u << (TX >> 2)) - 1u) << ((x0 >> 2) & 3);              // the tile's cells in one row of the macro-tile
+            uint32_t mask = 0;
+            for (int r = 0; r < (TY >> 2); r++) mask |= row << ((((y0 >> 2) & 3) + r) * 4);
+            cand = (~((uint32_t)cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) & mask) != 0u;
+        }
+        if (!cand) slots[pos].found = 0;
+    }
+    const unsigned long long b = __ballot(cand);
+    if (b == 0ULL) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&list[0], (uint32_t)__popcll(b));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (cand) list[1 + base + __popcll(b & ((1ULL << lane) - 1ULL))] = (uint32_t)pos;
+}
+
 // ---- one workgroup per tile: 128 threads for the 128-pixel shapes, one wave for the others -------------------------------------------
 // Thread t holds pixel t & (nPix - 1) in the order computeValues3D walks the tile (left 8 columns first for 16-wide tiles, :5856-5859); with
 // fewer than 64 pixels the wave holds the tile 64 / nPix times and every copy evaluates its own share of the patterns.
 __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
                                                             int w, int h, LutGeo g, const YkLutBank bank, uint32_t* __restrict__ covCh32, size_t covStride,
-                                                            int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap) {
+                                                            int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap,
+                                                            const uint32_t* __restrict__ list) {
     __shared__ __attribute__((aligned(16))) int s_cell[128];               // normalised 6-bit coordinates x | y << 8 | z << 16 of the live pixels, compacted
     __shared__ int s_box[6], s_n, s_csq, s_boxw[2][8];                     // s_boxw: per wave, packed minima of the box + live pixels
     __shared__ int s_best[4];                                               // pattern, orientation, bit mode, found
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     int* const s_mode = s_sum + nPat * 48;                                  // [nPat]: first orientation with the smallest score
     int (*const s_part)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPat);   // [2 waves][nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
     const int t = threadIdx.x, NT = blockDim.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;      // NT = 128, or 64 for tiles of at most 64 pixels
-    const uint32_t pos = blockIdx.x;
+    const uint32_t pos = list[1 + blockIdx.x];                               // the candidate tiles of the pass (yk_lut_list_kernel)
     const uint32_t blk = pos / (uint32_t)g.bitCount, tt = pos % (uint32_t)g.bitCount;
     const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
     const int y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(tt / (uint32_t)g.tilesPerRow) * TY;
@@ -466,7 +498,7 @@ static void yk_lut_release(yk_ctx* c) {
     YkLutState* S = c->lut; if (!S) return;
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int k = 0; k < S->nPat; k++) F(S->pat[k].dist);
-    F(S->ptab); F(S->pairMode); F(S->patStart); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->tileType); F(S->color);
+    F(S->ptab); F(S->pairMode); F(S->patStart); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->list); F(S->tileType); F(S->color);
     for (auto& p : S->idx) F(p);
     for (auto& p : S->map) F(p);
     delete S; c->lut = nullptr;
@@ -579,7 +611,7 @@ int yk_lut_start(yk_ctx* c) {
     if (w != S->capW || h != S->capH) {                      // a new image size: the streams, the maps and the per-pass scratch
         auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
         YK_HIP(c, hipStreamSynchronize(c->stream));
-        F(S->tileType); F(S->color); for (auto& p : S->idx) F(p); for (auto& p : S->map) F(p); F(S->slots); F(S->slotIdx); F(S->sums);
+        F(S->tileType); F(S->color); for (auto& p : S->idx) F(p); for (auto& p : S->map) F(p); F(S->slots); F(S->slotIdx); F(S->sums); F(S->list);
         S->capTiles = S->capPix = 0; S->capW = S->capH = 0;
         YK_HIP(c, hipMalloc(&S->tileType, capTiles * 2));
         YK_HIP(c, hipMalloc(&S->color, capTiles * 6));
@@ -594,6 +626,7 @@ int yk_lut_start(yk_ctx* c) {
         YK_HIP(c, hipMalloc(&S->slots, maxSlots * sizeof(LutSlot)));
         YK_HIP(c, hipMalloc(&S->slotIdx, (size_t)(w + 64) * (h + 64)));                      // slots x pixels per tile = whole swizzle blocks (64 x 64 at most), any shape
         YK_HIP(c, hipMalloc(&S->sums, (5 * ((maxSlots + 1023) / 1024) + 16) * sizeof(uint32_t)));
+        YK_HIP(c, hipMalloc(&S->list, (maxSlots + 1) * sizeof(uint32_t)));
         S->capTiles = capTiles; S->capPix = capPix; S->capW = w; S->capH = h;
     }
     for (int k = 0; k < 6; k++) YK_HIP(c, hipMemsetAsync(S->map[k], 0, S->mapBytes[k] + 16, c->stream));
@@ -616,10 +649,20 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     LutSlot* const slots = S->slots; uint8_t* const slotIdx = S->slotIdx; uint32_t* const sums = S->sums;    // yk_lut_start sized them
     YkLutBank bank; bank.ptab = S->ptab; bank.pairMode = S->pairMode; bank.patStart = S->patStart; bank.pos = S->posAll; bank.fac = S->facAll;
     bank.nPat = S->nPat; bank.nPairs = (int)S->hPairMode.size();
+    uint32_t nCand = 0;
+    YK_HIP(c, hipMemsetAsync(S->list, 0, sizeof(uint32_t), c->stream));
     { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_lut_search_kernel, dim3((unsigned)nSlots), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
-                       bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]));
+    hipLaunchKernelGGL(yk_lut_list_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, c->stream, c->covCh, c->covChStride, c->mtW, g, w, h, nSlots, slots, S->list);
     { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
+    YK_HIP(c, hipGetLastError());
+    YK_HIP(c, hipMemcpyAsync(&nCand, S->list, sizeof nCand, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));                              // the grid of the search is the number of candidates
+    if (nCand) {
+        { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
+        hipLaunchKernelGGL(yk_lut_search_kernel, dim3(nCand), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
+                           bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]), S->list);
+        { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
+    }
     hipLaunchKernelGGL(yk_lut_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, slots, nSlots, sums, nb);
     hipLaunchKernelGGL(yk_lut_scan_kernel, dim3(1), dim3(1024), 0, c->stream, sums, nb, sums + 5 * nb);
     LutStreams out; out.tileType = S->tileType; out.color = S->color; out.nType = S->nType; out.nColor = S->nColor;
