@@ -220,7 +220,9 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         const int cbit = ((gy >> 2) & 3) * 4 + ((gx >> 2) & 3);
         const uint16_t* cov = reinterpret_cast<const uint16_t*>(covCh32);
         liveP = !(((cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) >> cbit) & 1);
-        if (liveP) { const size_t pi = (size_t)gy * strideElems + gx; v[0] = pR[pi]; v[1] = pG[pi]; v[2] = pB[pi]; }
+        // samples are 0..255 by contract (framework.h:82, like every kernel of this library); the mask keeps the box, and with it every table
+        // index below, inside its range whatever the planes hold
+        if (liveP) { const size_t pi = (size_t)gy * strideElems + gx; v[0] = pR[pi] & 255; v[1] = pG[pi] & 255; v[2] = pB[pi] & 255; }
     }
     const bool live = liveP && t < nPix;
     const unsigned long long bal = __ballot(live);
