@@ -525,7 +525,7 @@ def main() -> int:
     # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh); only valid for the default workload
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/profile_round.sh writes profiles/traffic.json with the
     # SHA-256 of the kernel source it measured): reported only while that hash matches the kernel source in this tree, else null
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     if os.path.exists(tpath) and W == 8192 and not args.mode3 and K <= 2 and not BF:
         with open(tpath) as f:
@@ -533,12 +533,17 @@ def main() -> int:
         if tj.get("kernel") == "yk_encode2_kernel":
             if tj.get("kernel_source_sha256") == kernel_source_hash():
                 traffic, traffic_src = int(tj["hbm_traffic_bytes"]), tj.get("source")
+                valu = tj.get("valu_wave_instructions")
             else:
                 traffic_src = "stale: profiles/traffic.json was measured on another version of yk_encode2.hip (re-run tools/profile_round.sh)"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
                 "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (2 kernels)": round(kms["pack"], 4)}}
+    if valu and kms["encode"] > 0:
+        # the bound this kernel actually runs against: VALU issue.  Informational; `frac` above stays the HBM figure of the contract
+        roofline["valu_issue"] = {"wave_instructions": int(valu), "cycles_per_instruction": 4.15, "simds": 1024, "clock_ghz": 2.2,
+                                  "frac": round(valu * 4.15 / (1024 * kms["encode"] * 1e-3 * 2.2e9), 3), "source": tj.get("valu_source")}
     if BF:
         roofline["note"] = f"--batch {BF}: kernel times and algorithmic bytes are per launch = {BF} frames"
         roofline["algorithmic_bytes"] = int(alg_bytes) * BF

@@ -22,6 +22,8 @@ print(json.dumps({"kernel": "yk_encode2_kernel", "hbm_traffic_bytes": d["hbm_tra
                   "write_bytes_corrected": d["write_bytes_corrected"], "avg_ns_rocprof": d["avg_ns"],
                   "kernel_source_sha256": hashlib.sha256(open("yaik_amd/csrc/yk_encode2.hip", "rb").read()).hexdigest(),
                   "workload": "8192x8192 RGBA, bench.py defaults (two frames in flight, fused kernels ordered)",
+                  "valu_wave_instructions": int(d["SQ_INSTS_VALU"]),
+                  "valu_source": "SQ_INSTS_VALU of the same PMC run; 4.15 cycles per packed-16 / 32-bit integer wave-instruction per SIMD (profiles/r02/op_rate_gfx950.txt), 1024 SIMDs, 2.2 GHz shader clock under this kernel (profiles/r01/j_wave_timeline.txt)",
                   "source": f"profiles/{tag[:3]}/{tag[3:]}_pmc_and_stats_summary.json (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950, KB -> bytes)"}, indent=1))
 PY
 cat gpurun_out/traffic_$TAG.json
