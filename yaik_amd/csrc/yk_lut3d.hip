@@ -157,31 +157,38 @@ struct LutSlot { uint16_t type; uint8_t box[6]; uint8_t mode; uint8_t pixels; ui
 // lies inside one 16x16 macro-tile, so its cells are a mask of that macro-tile's coverage words.  The others get their "not found" here: the
 // search kernel is launched for the candidates only (on the bench frame half of the 4.2 M 4x4 slots have nothing left to code, and an empty
 // workgroup still costs its dispatch).  list[0] = count (zeroed by the caller), list[1..] in any order: the results go to per-slot records.
-__global__ __launch_bounds__(256) void yk_lut_list_kernel(const uint16_t* __restrict__ cov, size_t covStride, int mtW, LutGeo g, int w, int h, size_t nSlots,
-                                                          LutSlot* __restrict__ slots, uint32_t* __restrict__ list) {
-    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool cand = false;
-    if (pos < nSlots) {
-        const int TX = 1 << g.sx, TY = 1 << g.sy;
+__global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __restrict__ cov, size_t covStride, int mtW, LutGeo g, int w, int h, size_t nSlots,
+                                                           LutSlot* __restrict__ slots, uint32_t* __restrict__ list) {
+    __shared__ uint32_t s_tmp[32], s_base;
+    // four consecutive slots per thread and ONE atomic per workgroup of 4096 slots: a single address sustains about 88 atomics per
+    // microsecond, one per wave of 64 slots made this kernel 0.3 ms for the 4x4 pass
+    const size_t pos0 = ((size_t)blockIdx.x * 1024 + threadIdx.x) * 4;
+    const int TX = 1 << g.sx, TY = 1 << g.sy;
+    uint32_t cand = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const size_t pos = pos0 + r;
+        if (pos >= nSlots) break;
         const uint32_t blk = (uint32_t)(pos / (uint32_t)g.bitCount), tt = (uint32_t)(pos % (uint32_t)g.bitCount);
         const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
         const int y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(tt / (uint32_t)g.tilesPerRow) * TY;
+        bool c = false;
         if (x0 + TX <= w && y0 + TY <= h) {                                  // partial tiles are never tried (:6304, :6311)
             const size_t mt = (size_t)(y0 >> 4) * mtW + (x0 >> 4);
             const uint32_t row = ((1u << (TX >> 2)) - 1u) << ((x0 >> 2) & 3);              // the tile's cells in one row of the macro-tile
             uint32_t mask = 0;
-            for (int r = 0; r < (TY >> 2); r++) mask |= row << ((((y0 >> 2) & 3) + r) * 4);
-            cand = (~((uint32_t)cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) & mask) != 0u;
+            for (int q = 0; q < (TY >> 2); q++) mask |= row << ((((y0 >> 2) & 3) + q) * 4);
+            c = (~((uint32_t)cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) & mask) != 0u;
         }
-        if (!cand) slots[pos].found = 0;
+        if (c) cand |= 1u << r; else slots[pos].found = 0;
     }
-    const unsigned long long b = __ballot(cand);
-    if (b == 0ULL) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&list[0], (uint32_t)__popcll(b));
-    base = (uint32_t)__shfl((int)base, 0);
-    if (cand) list[1 + base + __popcll(b & ((1ULL << lane) - 1ULL))] = (uint32_t)pos;
+    uint32_t tot;
+    const uint32_t ex = yk_block_exscan((uint32_t)__popc(cand), s_tmp, &tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&list[0], tot) : 0u;
+    __syncthreads();
+    uint32_t o = 1u + s_base + ex;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if ((cand >> r) & 1u) list[o++] = (uint32_t)(pos0 + r);
 }
 
 // ---- one workgroup per tile: 128 threads for the 128-pixel shapes, one wave for the others -------------------------------------------
@@ -654,7 +661,7 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     uint32_t nCand = 0;
     YK_HIP(c, hipMemsetAsync(S->list, 0, sizeof(uint32_t), c->stream));
     { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
-    hipLaunchKernelGGL(yk_lut_list_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, c->stream, c->covCh, c->covChStride, c->mtW, g, w, h, nSlots, slots, S->list);
+    hipLaunchKernelGGL(yk_lut_list_kernel, dim3((unsigned)((nSlots + 4095) / 4096)), dim3(1024), 0, c->stream, c->covCh, c->covChStride, c->mtW, g, w, h, nSlots, slots, S->list);
     { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
     YK_HIP(c, hipGetLastError());
     YK_HIP(c, hipMemcpyAsync(&nCand, S->list, sizeof nCand, hipMemcpyDeviceToHost, c->stream));
