@@ -426,6 +426,10 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
 
     const int lane = threadIdx.x;
+    // A new wave is the youngest of its SIMD: with equal priorities the arbiter lets the older waves' arithmetic go first and the 18
+    // loads below leave only when those stall.  Until they are issued the wave runs at the highest priority (the ~60 instructions it
+    // takes cost the others nothing measurable; the pixels arrive that much earlier: -2 % on the frame, -4 % on noise).
+    __builtin_amdgcn_s_setprio(3);
 #ifdef YK2_TIMING
     const unsigned long long y2_t_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned y2_hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), y2_xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
@@ -501,6 +505,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             hcol = (uint32_t)*reinterpret_cast<const int32_t*>(b0 + off) | ((uint32_t)*reinterpret_cast<const int32_t*>(b1 + off) << 8) |
                    ((uint32_t)*reinterpret_cast<const int32_t*>(b2 + off) << 16);
         }
+        __builtin_amdgcn_s_setprio(0);                                       // all loads are out
         if (BX * 64 + 64 > w) {                                              // wave-uniform: lanes beyond the right edge replicate column w - 1
             if (!inX) {
 #pragma unroll
