@@ -326,6 +326,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
 #define YK2_QROWS 258
 #define YK2_QR0 32
 #define YK2_QNR 224
+#define YK2_QBYTES ((size_t)YK2_QNR * YK2_QROWS * 16)
 __global__ void yk_qtab_kernel(uint4* tab) {
     __shared__ int K[6][16];
     const int R = YK2_QR0 + (int)blockIdx.x, t = threadIdx.x;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     __shared__ uint32_t s_bm[24];
     __shared__ uint8_t s_list[64];                                          // gradient passes with few viable cells: their lanes, compacted
     __shared__ __attribute__((aligned(16))) float s_curve[6][16];
-    __shared__ float s_rcp[256];                                            // RN(1 / pixel value); [0] = 0 (skipped term, :884)
+    __shared__ __attribute__((aligned(16))) float s_rcp[256];               // RN(1 / pixel value); [0] = 0 (skipped term, :884); correctly rounded: the exact path needs that
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
     // time) and its mode sums
     __shared__ __attribute__((aligned(16))) uint32_t s_aux[432];
@@ -505,6 +506,9 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             hcol = (uint32_t)*reinterpret_cast<const int32_t*>(b0 + off) | ((uint32_t)*reinterpret_cast<const int32_t*>(b1 + off) << 8) |
                    ((uint32_t)*reinterpret_cast<const int32_t*>(b2 + off) << 16);
         }
+        // the reciprocals of the range phase's error terms ride along (every strip pays one load and one LDS store; a coded strip used to
+        // compute its 256 quotients itself, four correctly rounded divisions per lane)
+        const float4 rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
         __builtin_amdgcn_s_setprio(0);                                       // all loads are out
         if (BX * 64 + 64 > w) {                                              // wave-uniform: lanes beyond the right edge replicate column w - 1
             if (!inX) {
@@ -531,6 +535,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = o;
         }
         if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
+        *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
@@ -701,9 +706,6 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.qtab, 0, YK2_QNR * YK2_QROWS * 16, 0x00020000);
 #endif
         const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const int v = k * 64 + lane; s_rcp[v] = v ? __fdiv_rn(1.0f, (float)v) : 0.0f; }   // correctly rounded: the exact path needs that
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t slotOff[4];                                                 // byte offset of the lane's four nibble rows inside the plane's slot array
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -957,8 +959,13 @@ int yk_qtab_get(yk_ctx* c) {
     if (c->device < 0 || c->device >= 64) return yk_fail(c, YK_ERR_BAD_ARG, "device index");
     if (!g_qtab[c->device]) {
         uint8_t* t = nullptr;
-        YK_HIP(c, hipMalloc(&t, (size_t)YK2_QNR * YK2_QROWS * 16));
+        YK_HIP(c, hipMalloc(&t, YK2_QBYTES + 256 * sizeof(float)));
         hipLaunchKernelGGL(yk_qtab_kernel, dim3(YK2_QNR), dim3(320), 0, c->stream, reinterpret_cast<uint4*>(t));
+        {   // behind the rows: RN(1 / v) for v = 1..255, [0] = 0 (a skipped term, :884); IEEE division on the host = __fdiv_rn
+            float rcp[256]; rcp[0] = 0.0f;
+            for (int v = 1; v < 256; v++) rcp[v] = 1.0f / (float)v;
+            YK_HIP(c, hipMemcpyAsync(t + YK2_QBYTES, rcp, sizeof rcp, hipMemcpyHostToDevice, c->stream));
+        }
         YK_HIP(c, hipGetLastError());
         YK_HIP(c, hipStreamSynchronize(c->stream));
         g_qtab[c->device] = t;
