@@ -11,7 +11,9 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libyaik_hip.so")
+# YK_LIB=/path/to/variant.so selects another build of the same C-ABI (same-box A/B runs, instrumented builds): the product
+# library in the tree is never overwritten by an experiment (tools/ab.sh).
+LIB_PATH = os.environ.get("YK_LIB") or os.path.join(HERE, "libyaik_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 

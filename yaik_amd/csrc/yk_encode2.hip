@@ -30,15 +30,6 @@ __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
 // |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
 __device__ __forceinline__ uint32_t y2_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// Values of the other lanes of an 8x8 tile {l, l^1, l^4, l^5} through DPP instead of the LDS crossbar (ds_bpermute): lane^1 is a
-// quad permutation; lane^4 is row_shl:4 for the quads with bit 2 clear and row_shr:4 for the others (bank masks select them).
-__device__ __forceinline__ int y2_lane_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }          // quad_perm:[1,0,3,2]
-__device__ __forceinline__ int y2_lane_xor4(int v) {
-    const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);                                                       // row_shl:4, banks 0 and 2
-    return __builtin_amdgcn_update_dpp(up, v, 0x114, 0xF, 0xA, false);                                                              // row_shr:4, banks 1 and 3
-}
-__device__ __forceinline__ float y2_lane_xor1(float v) { return __int_as_float(y2_lane_xor1(__float_as_int(v))); }
-__device__ __forceinline__ float y2_lane_xor4(float v) { return __int_as_float(y2_lane_xor4(__float_as_int(v))); }
 __device__ __forceinline__ int y2_round6(int v) { return (v & ~3) | (v >> 6); }                       // EncoderContext.cpp:3183
 __device__ __forceinline__ int y2_round6p(int v) { v = min(v + 1, 255); return (v & ~3) | (v >> 6); } // EncoderContext.cpp:3202
 
@@ -60,25 +51,40 @@ __device__ __forceinline__ y2s2 y2_s2(y2u2 v) { return __builtin_bit_cast(y2s2, 
 __device__ __forceinline__ y2u2 y2_splat(int v) { const unsigned short t = (unsigned short)v; return (y2u2){ t, t }; }
 __device__ __forceinline__ y2s2 y2_splats(int v) { const short t = (short)v; return (y2s2){ t, t }; }
 #define YK2_LATN 85                                                      // 17 x 5 lattice points (every 4th pixel incl. the halo) per strip
+// -DYK2_STATS (tools/path_stats.py only, never shipped): how often every path of the kernel is taken, summed over the launch
+#ifdef YK2_STATS
+__device__ unsigned long long g_y2_stats[128];
+#define YK2_STAT(i, n) do { if (lane == 0) atomicAdd(&g_y2_stats[(i)], (unsigned long long)(n)); } while (0)
+extern "C" int yk_debug_path_stats(unsigned long long* out, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_y2_stats), sizeof(g_y2_stats));
+    if (e == hipSuccess && clear) { static unsigned long long z[128]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_y2_stats), z, sizeof(z)); }
+    return (int)e;
+}
+#else
+#define YK2_STAT(i, n) do { } while (0)
+#endif
 
-// Tile-level decisions as wave-uniform 64-bit lane masks on the scalar unit (lane = macroTile*16 + cellY*4 + cellX): a tile of NX x NY
-// cells is represented by the bit of its origin cell's lane.
+// Tile-level decisions as wave-uniform 64-bit lane masks on the scalar unit.  Lane order inside a macro-tile is MORTON:
+// lane = macroTile*16 + (cellY>>1)*8 + (cellX>>1)*4 + (cellY&1)*2 + (cellX&1), so that an 8x8 tile (2x2 cells) is one quad of lanes and its
+// reductions are quad_perm DPP operands of the ALU instruction itself.  A tile of NX x NY cells is represented by the bit of its origin cell's lane.
+__device__ __forceinline__ constexpr int y2_cell_x(int m) { return (m & 1) | ((m >> 1) & 2); }
+__device__ __forceinline__ constexpr int y2_cell_y(int m) { return ((m >> 1) & 1) | ((m >> 2) & 2); }
 template <int NX, int NY> __device__ __forceinline__ constexpr unsigned long long y2_origin() {      // lanes that are tile origins
     unsigned long long m = 0;
-    for (int y = 0; y < 4; y += NY) for (int x = 0; x < 4; x += NX) m |= 1ULL << (y * 4 + x);
+    for (int i = 0; i < 16; i++) if ((y2_cell_x(i) % NX) == 0 && (y2_cell_y(i) % NY) == 0) m |= 1ULL << i;
     return m * 0x0001000100010001ULL;
 }
 template <int NX, int NY> __device__ __forceinline__ unsigned long long y2_fold(unsigned long long m) {   // origin bit <- OR over the tile's lanes
     if (NX >= 2) m |= m >> 1;
-    if (NX == 4) m |= m >> 2;
-    if (NY >= 2) m |= m >> 4;
+    if (NY >= 2) m |= m >> 2;
+    if (NX == 4) m |= m >> 4;
     if (NY == 4) m |= m >> 8;
     return m;                                                            // only the origin bits are meaningful
 }
 template <int NX, int NY> __device__ __forceinline__ unsigned long long y2_spread(unsigned long long m) { // origin bits -> all lanes of the tile
     if (NX >= 2) m |= m << 1;
-    if (NX == 4) m |= m << 2;
-    if (NY >= 2) m |= m << 4;
+    if (NY >= 2) m |= m << 2;
+    if (NX == 4) m |= m << 4;
     if (NY == 4) m |= m << 8;
     return m;
 }
@@ -98,6 +104,8 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         viable &= __ballot((tgx + TX <= w) && (tgy + TY <= h));
     }
     if (viable == 0ULL) return;
+    constexpr int kPassId = (SX == 4 && SY == 4) ? 0 : (SX == 4 && SY == 3) ? 1 : (SX == 3 && SY == 4) ? 2 : (SX == 3 && SY == 3) ? 3 : (SX == 3 && SY == 2) ? 4 : (SX == 2 && SY == 3) ? 5 : 6;
+    YK2_STAT(kPassId * 10 + 0, 1); YK2_STAT(kPassId * 10 + 8, __popcll(y2_spread<NX, NY>(viable)));
     const int loO = -256 * rf, hiO = 256 * rf + 255;
     const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
 
@@ -109,6 +117,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     const unsigned long long cells = y2_spread<NX, NY>(viable);
     const int nCells = __popcll(cells);
     if (nCells <= 16) {
+        YK2_STAT(kPassId * 10 + 1, 1); YK2_STAT(kPassId * 10 + 7, nCells);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cells >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cells, 0u));
         const bool mine = __builtin_amdgcn_inverse_ballot_w64(cells);
         if (mine) s_list[rank] = (uint8_t)lane;
@@ -116,7 +125,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         const int j = lane & 15, r = lane >> 4;
         const bool act = j < nCells;
         const int c = (int)s_list[act ? j : 0];
-        const int q2 = c >> 4, cy2 = (c >> 2) & 3, cx2 = c & 3;
+        const int q2 = c >> 4, cy2 = y2_cell_y(c & 15), cx2 = y2_cell_x(c & 15);
         const int dcx2 = cx2 & (NX - 1), dcy2 = cy2 & (NY - 1);
         const int lo2 = cy2 * 17 + q2 * 4 + cx2 - dcy2 * 17 - dcx2;          // lattice index of the tile origin
         const y2u2 wyr = y2_splat(16 - ((dcy2 * 4 + r) << (4 - SY)));       // weight of row r of the cell
@@ -262,11 +271,11 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         setup(0); setup(3);
         pixelRow(0, 0x09u, true);
         viable &= ~(failA4(mn[0], mx[0]) & failP2(mn[3], mx[3]));
-        if (viable == 0ULL) return;
+        if (viable == 0ULL) { YK2_STAT(kPassId * 10 + 2, 1); return; }
         setup(1); setup(2);
         pixelRow(0, 0x06u, true);
         viable &= ~(failA4(mnAll(), mxAll()) & failP2(mn[3], mx[3]));      // after one row: lost tiles cannot be accepted by later rows
-        if (viable == 0ULL) return;
+        if (viable == 0ULL) { YK2_STAT(kPassId * 10 + 3, 1); return; }
         nextRow(0, kA);
         pixelRow(1, kA, false);
         pRows = 0;                                                       // stream 3 has walked row 0, stream 4 nothing yet
@@ -275,15 +284,16 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         for (int t = 0; t < 5; t++) setup(t);
         pixelRow(0, 0x1Fu, true);
         viable &= ~(failA4(mnAll(), mxAll()) & failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4])));
-        if (viable == 0ULL) return;
+        if (viable == 0ULL) { YK2_STAT(kPassId * 10 + 3, 1); return; }
         nextRow(0, 0x1Fu);
         pixelRow(1, 0x1Fu, false);
         if (NX * NY == 1) {                                              // 4x4 tiles: one lane per tile, a second look after half of the tile
             viable &= ~(failA4(mnAll(), mxAll()) & failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4])));
-            if (viable == 0ULL) return;
+            if (viable == 0ULL) { YK2_STAT(kPassId * 10 + 9, 1); return; }
         }
         pRows = 2;
     }
+    YK2_STAT(kPassId * 10 + 4, 1);
     nextRow(1, kA);
     pixelRow(2, kA, false);
     nextRow(2, kA);
@@ -291,6 +301,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     unsigned long long accept = viable & ~failA4(mnAll(), mxAll());      // some raw / Round6 variant never failed (:3998)
     const unsigned long long rest = viable & ~accept;
     if (rest != 0ULL) {                                                  // wave-uniform: the Round6P variants decide the remaining tiles
+        YK2_STAT(kPassId * 10 + 5, 1); YK2_STAT(90 + kPassId, __popcll(y2_spread<NX, NY>(rest)));
         if (kScreen) {
             setup(4);
             pixelRow(0, 0x10u, true);
@@ -305,6 +316,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     }
     (void)pRows;
     if (accept == 0ULL) return;
+    YK2_STAT(kPassId * 10 + 6, 1);
     cov |= y2_spread<NX, NY>(accept);                                    // paint coverage (:4029-4037): bit = lane = cell
     if (__builtin_amdgcn_inverse_ballot_w64(accept)) {                   // the origin cell's lane sets the bitmap bit (:4026)
         const int tbx = bxCell >> SX, tby = byCell >> SY;                // tile coordinates inside the 64x64 block
@@ -322,11 +334,21 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
 
 // ---- quantiser table: for every rangeDecode R (32..255) and every offset o = v - BN (-2..255) the index and minDiff of the first
 // nearest entry of the six LUTs BN + K[R][mode][i], K = trunc(curve * R) (DynamicTile::buildTable, EncoderContext.cpp:662-696, and
-// the `<` scan of GetTileDynamic_Y, :873-881).  Row = 16 bytes: minDiff of modes 0..3 | minDiff of modes 4, 5 | six index nibbles | 0.
+// the `<` scan of GetTileDynamic_Y, :873-881).  Row = 16 bytes: minDiff of modes 0..5 as six f16 (exact integers; v_fma_mix_f32 takes
+// them as they are, a byte would need a conversion instruction per mode and pixel) | six index nibbles | 0.
 #define YK2_QROWS 258
 #define YK2_QR0 32
 #define YK2_QNR 224
 #define YK2_QBYTES ((size_t)YK2_QNR * YK2_QROWS * 16)
+#define YK2_RCPBYTES ((size_t)256 * sizeof(float))
+// ---- tile-definition table: DynamicTile::buildTable's integer part (:625-661) for every (min_, d8) a tile can have, min_ = min(min, 224) in
+// 0..224, d8 = max(max - min_, 32) in 32..255: [first row of the tile's slab in the quantiser table + 256 - BN + 2 (16 bits) | EncodeTileType's
+// range and base fields (15 bits)].  One 4-byte gather per tile-plane instead of ~40 instructions of divisions by constants per lane.
+#define YK2_DEFN1 224
+#define YK2_DEFBYTES ((size_t)225 * YK2_DEFN1 * 4)
+#define YK2_TABBYTES (YK2_QBYTES + YK2_RCPBYTES + YK2_DEFBYTES)
+typedef _Float16 y2h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t y2_f16_bits(int n) { const _Float16 h = (_Float16)(float)n; return (uint32_t)__builtin_bit_cast(unsigned short, h); }
 __global__ void yk_qtab_kernel(uint4* tab) {
     __shared__ int K[6][16];
     const int R = YK2_QR0 + (int)blockIdx.x, t = threadIdx.x;
@@ -334,35 +356,55 @@ __global__ void yk_qtab_kernel(uint4* tab) {
     __syncthreads();
     if (t < YK2_QROWS) {
         const int o = t - 2;
-        uint32_t md03 = 0, md45 = 0, idx = 0;
+        uint32_t md[6], idx = 0;
         for (int m = 0; m < 6; m++) {
             const int cnt = m < 3 ? 16 : 8;
             int best = 1 << 30, bi = 0;
             for (int n = 0; n < cnt; n++) { const int d = abs(K[m][n] - o); if (d < best) { best = d; bi = n; } }
             best = min(best, 255);                                       // only offsets no tile can reach exceed a byte
-            if (m < 4) md03 |= (uint32_t)best << (8 * m); else md45 |= (uint32_t)best << (8 * (m - 4));
+            md[m] = y2_f16_bits(best);
             idx |= (uint32_t)bi << (4 * m);
         }
-        tab[(size_t)blockIdx.x * YK2_QROWS + t] = make_uint4(md03, md45, idx, 0u);
+        tab[(size_t)blockIdx.x * YK2_QROWS + t] = make_uint4(md[0] | (md[1] << 16), md[2] | (md[3] << 16), md[4] | (md[5] << 16), idx);
     }
 }
+// the integer part of DynamicTile::buildTable for a tile whose valid pixels span [mn, mx] (EncoderContext.cpp:625-661)
+struct Y2TileDef { int base, BN, dist, R; };
+__device__ __forceinline__ Y2TileDef y2_tile_def(const int min_, const int d8) {
+    Y2TileDef d;
+    d.base = (min_ * 63 + 112) / 224;
+    d.BN = (d.base * 224) / 63;
+    const int scale = 223 - d.BN;
+    const int dnum = (d8 - 32) * 127 + (scale - 1);
+    d.dist = (scale < 0) ? -dnum : dnum / scale;
+    d.R = (d.dist * scale) / 127 + 32;
+    return d;
+}
+__global__ void yk_deftab_kernel(uint32_t* tab) {
+    const int min_ = blockIdx.x, d8 = 32 + (int)threadIdx.x;
+    const Y2TileDef d = y2_tile_def(min_, d8);
+    const int R = min(max(d.R, YK2_QR0), YK2_QR0 + YK2_QNR - 1);         // pairs no tile can have (checked by yk_selftest 3) stay inside the table
+    const uint32_t rowBase = (uint32_t)((R - YK2_QR0) * YK2_QROWS + 2 - d.BN + 256);
+    tab[min_ * YK2_DEFN1 + (int)threadIdx.x] = rowBase | (((((uint32_t)d.dist & 255u) << 7) | ((uint32_t)d.base & 255u)) << 16);
+}
 
-// yk_selftest 3: for every (min, max) of a tile, the LUTs built the reference's way (float add of BN) equal BN + K[rangeDecode]
-// and every value of the tile finds, in the table, the entry a scan of those LUTs finds.
-__global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
+// yk_selftest 3: for every (min, max) of a tile, the LUTs built the reference's way (float add of BN) equal BN + K[rangeDecode],
+// every value of the tile finds, in the table, the entry a scan of those LUTs finds, and the tile-definition table holds the tile's slab and fields.
+__global__ void yk_selftest_qtab_kernel(const uint4* tab, const uint32_t* deftab, int* mismatches) {
     const int mn = blockIdx.x, mx = threadIdx.x;
     if (mx < mn) return;
     const int min_ = min(mn, 224);
     int diff = mx - min_; if (diff < 16) diff = 16;
-    const int base = (min_ * 63 + 112) / 224;
-    const int BN = (base * 224) / 63;
     const int d8 = max(diff, 32);
-    const int scale = 223 - BN;
-    const int dnum = (d8 - 32) * 127 + (scale - 1);
-    const int dist = (scale < 0) ? -dnum : dnum / scale;
-    const int R = (dist * scale) / 127 + 32;
+    const Y2TileDef d = y2_tile_def(min_, d8);
+    const int BN = d.BN, R = d.R;
     int bad = 0;
     if (R < YK2_QR0 || R >= YK2_QR0 + YK2_QNR || mn - BN < -2) { atomicAdd(mismatches, 1); return; }
+    {
+        const uint32_t e = deftab[min_ * YK2_DEFN1 + (d8 - 32)];
+        if ((e & 0xFFFFu) != (uint32_t)((R - YK2_QR0) * YK2_QROWS + 2 - BN + 256)) bad++;
+        if ((e >> 16) != ((((uint32_t)d.dist & 255u) << 7) | ((uint32_t)d.base & 255u))) bad++;
+    }
     for (int m = 0; m < 6; m++) {
         const int cnt = m < 3 ? 16 : 8;
         int L[16];
@@ -372,22 +414,17 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, int* mismatches) {
         }
         for (int v = mn; v <= mx; v++) {
             int best = 1 << 30, bi = 0;
-            for (int n = 0; n < cnt; n++) { const int d = abs(L[n] - v); if (d < best) { best = d; bi = n; } }
+            for (int n = 0; n < cnt; n++) { const int dd = abs(L[n] - v); if (dd < best) { best = dd; bi = n; } }
             const uint4 row = tab[(size_t)(R - YK2_QR0) * YK2_QROWS + (v - BN + 2)];
-            const int md = m < 4 ? (row.x >> (8 * m)) & 255 : (row.y >> (8 * (m - 4))) & 255;
-            const int ix = (row.z >> (4 * m)) & 15;
-            if (md != best || ix != bi) bad++;
+            const uint32_t w = m < 2 ? row.x : (m < 4 ? row.y : row.z);
+            const uint32_t hb = (m & 1) ? (w >> 16) : (w & 0xFFFFu);
+            const int ix = (row.w >> (4 * m)) & 15;
+            if (hb != y2_f16_bits(best) || ix != bi) bad++;
         }
     }
     if (bad) atomicAdd(mismatches, bad);
 }
 
-// Cache policy of the quantiser-table gathers (experiment switch): 0 = plain global loads; n > 0 = buffer loads
-// with aux = n (1 sc0, 2 nt, 16 sc1)
-#ifndef YK2_QPOL
-#define YK2_QPOL 0
-#endif
-typedef uint32_t y2u3 __attribute__((ext_vector_type(3)));
 #define YK2_RUN 16
 // -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
 // five points, its entry time and its hardware slot (HW_ID, XCC_ID) into a device array that yk_debug_wave_times copies out.
@@ -399,25 +436,51 @@ extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMem
 #define YK2_PROBE(i) do { } while (0)
 #endif
 #define YK2_LUTW 84
+#ifndef YK2_WIN
+#define YK2_WIN 16
+#endif
+#ifndef YK2_RVWIN
+#define YK2_RVWIN 8
+#endif
+
+// values of the other lanes of the lane's quad (= its 8x8 tile) as DPP operands
+#define Y2_QUAD_X 0xB1                                                   // quad_perm:[1,0,3,2]: the cell beside this one
+#define Y2_QUAD_Y 0x4E                                                   // quad_perm:[2,3,0,1]: the cell above / below
+template <int CTRL> __device__ __forceinline__ int y2_quad(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ float y2_quad(float v) { return __int_as_float(y2_quad<CTRL>(__float_as_int(v))); }
+// 4 * byte `ch` of w in one instruction (SDWA byte select feeding the shift)
+__device__ __forceinline__ uint32_t y2_byte_x4(uint32_t w, int ch) {
+    uint32_t r; const uint32_t two = 2u;
+    if (ch == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    else if (ch == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+// acc = fma((float)half(h), w, acc), half = low / high 16 bits of h as f16: v_fma_mix_f32 converts inside the operation
+__device__ __forceinline__ void y2_fma_lo(float& acc, uint32_t h, float w) { asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "v"(w)); }
+__device__ __forceinline__ void y2_fma_hi(float& acc, uint32_t h, float w) { asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "v"(w)); }
+// R | G << 8 | B << 16 of three samples in 0..255 (two byte permutations)
+__device__ __forceinline__ uint32_t y2_pack3(int r, int g, int b) {
+    return __builtin_amdgcn_perm((uint32_t)b, __builtin_amdgcn_perm((uint32_t)g, (uint32_t)r, 0x0C0C0400u), 0x0C040100u);
+}
 
 // WANT_DST: the test-only reconstruction of the coded pixels into P.dst (yk_range_dst).  It is a separate instantiation because its extra
-// live state costs the product kernel 8 spilled VGPRs, and with them a scratch allocation per wave launch.
-template <bool WANT_DST>
+// live state costs the product kernel spilled VGPRs, and with them a scratch allocation per wave launch.
+// MODE3: DynamicTileEncode's mode3BitOnly (modes 3..5 only).
+template <bool WANT_DST, bool MODE3>
 __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams P) {
     // One wave64 per workgroup: a work unit is a 64x16 strip (four macro-tiles) of a 64x64 swizzle block, so nothing in the
     // kernel waits on another wave.  The staged pixels are only read by the gradient passes (afterwards every lane holds its
-    // 16 pixels in registers), so the range quantiser's LUTs reuse the same LDS.
-    // LUT layout per 8x8 tile: 4-bit mode m at [20m, 20m+16) + its three quarter thresholds at [20m+16, 20m+19);
-    // 3-bit mode m at [60+8(m-3), +8).  Entries are LUT << 8, thresholds (LUT[4j+3] + LUT[4j+4]) << 7 (the midpoint, same units).
-    // (Waves that walk 2 or 4 consecutive strips instead of ending after one were measured again with this kernel: the loop costs
-    // ~25 spilled registers and the frame gets 8-25 % slower)
-    constexpr int kPixWords = 17 * LS, kLutWords = 16 * YK2_LUTW;
+    // 16 pixels in registers), so the test build's LUTs reuse the same LDS.
+    // LUT layout per 8x8 tile (WANT_DST only): 4-bit mode m at [20m, 20m+16), 3-bit mode m at [60+8(m-3), +8); entries are LUT << 8.
+    constexpr int kStart = MODE3 ? 3 : 0;
+    constexpr int kPixWords = 17 * LS, kLutWords = WANT_DST ? 16 * YK2_LUTW : 0;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kPixWords > kLutWords ? kPixWords : kLutWords];
     uint32_t* const s_pix = s_mem;
     uint32_t (*const s_lut)[YK2_LUTW] = reinterpret_cast<uint32_t (*)[YK2_LUTW]>(s_mem);
     __shared__ uint32_t s_bm[24];
     __shared__ uint8_t s_list[64];                                          // gradient passes with few viable cells: their lanes, compacted
-    __shared__ __attribute__((aligned(16))) float s_curve[6][16];
+    __shared__ __attribute__((aligned(16))) float s_curve[WANT_DST ? 6 : 1][16];
     __shared__ __attribute__((aligned(16))) float s_rcp[256];               // RN(1 / pixel value); [0] = 0 (skipped term, :884); correctly rounded: the exact path needs that
     // gradient phase: the corner lattice in stream layout (5 x 85 words); range phase: exact-order fallback (one tile-plane at a
     // time) and its mode sums
@@ -425,6 +488,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     uint32_t* const s_lat = s_aux;
     float (*const s_chain)[68] = reinterpret_cast<float (*)[68]>(s_aux);
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
+    __shared__ uint32_t s_range[3 * 64];
+    uint32_t* const s_tile = s_aux + 416;                                    // exact-order fallback: the 64 values of the tile-plane being re-summed
+    // range phase: the index words of a plane's sixteen rows per lane; the staged pixels are dead by then (the test build's LUTs live there)
+    __shared__ uint32_t s_iwTest[WANT_DST ? 1024 : 1];
+    uint32_t* const s_iw = WANT_DST ? s_iwTest : s_mem;
+    static_assert(WANT_DST || kPixWords >= 1024, "index words need 4 KB");
 
     const int lane = threadIdx.x;
     // A new wave is the youngest of its SIMD: with equal priorities the arbiter lets the older waves' arithmetic go first and the 18
@@ -503,36 +572,26 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         {
             const int rel = min(gyS + hr, P.hAvail - 1) - gyB;
             const uint32_t off = (uint32_t)(rel * P.strideElems + min(BX * 64 + 64, w - 1)) * 4u;
-            hcol = (uint32_t)*reinterpret_cast<const int32_t*>(b0 + off) | ((uint32_t)*reinterpret_cast<const int32_t*>(b1 + off) << 8) |
-                   ((uint32_t)*reinterpret_cast<const int32_t*>(b2 + off) << 16);
+            hcol = y2_pack3(*reinterpret_cast<const int32_t*>(b0 + off), *reinterpret_cast<const int32_t*>(b1 + off), *reinterpret_cast<const int32_t*>(b2 + off));
         }
         // the reciprocals of the range phase's error terms ride along (every strip pays one load and one LDS store; a coded strip used to
         // compute its 256 quotients itself, four correctly rounded divisions per lane)
         const float4 rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
         __builtin_amdgcn_s_setprio(0);                                       // all loads are out
-        if (BX * 64 + 64 > w) {                                              // wave-uniform: lanes beyond the right edge replicate column w - 1
-            if (!inX) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    R[k] = make_int4(R[k].w, R[k].w, R[k].w, R[k].w); G[k] = make_int4(G[k].w, G[k].w, G[k].w, G[k].w); B[k] = make_int4(B[k].w, B[k].w, B[k].w, B[k].w);
-                }
-                Rb = make_int4(Rb.w, Rb.w, Rb.w, Rb.w); Gb = make_int4(Gb.w, Gb.w, Gb.w, Gb.w); Bb = make_int4(Bb.w, Bb.w, Bb.w, Bb.w);
-            }
-        }
+        uint4 o[4], ob;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint4 o = make_uint4((uint32_t)R[k].x | ((uint32_t)G[k].x << 8) | ((uint32_t)B[k].x << 16),
-                                       (uint32_t)R[k].y | ((uint32_t)G[k].y << 8) | ((uint32_t)B[k].y << 16),
-                                       (uint32_t)R[k].z | ((uint32_t)G[k].z << 8) | ((uint32_t)B[k].z << 16),
-                                       (uint32_t)R[k].w | ((uint32_t)G[k].w << 8) | ((uint32_t)B[k].w << 16));
-            *reinterpret_cast<uint4*>(&s_pix[(r0 + 4 * k) * LS + g4]) = o;
+            o[k] = make_uint4(y2_pack3(R[k].x, G[k].x, B[k].x), y2_pack3(R[k].y, G[k].y, B[k].y), y2_pack3(R[k].z, G[k].z, B[k].z), y2_pack3(R[k].w, G[k].w, B[k].w));
+            *reinterpret_cast<uint4*>(&s_pix[(r0 + 4 * k) * LS + g4]) = o[k];
         }
-        if (lane < 16) {
-            const uint4 o = make_uint4((uint32_t)Rb.x | ((uint32_t)Gb.x << 8) | ((uint32_t)Bb.x << 16),
-                                       (uint32_t)Rb.y | ((uint32_t)Gb.y << 8) | ((uint32_t)Bb.y << 16),
-                                       (uint32_t)Rb.z | ((uint32_t)Gb.z << 8) | ((uint32_t)Bb.z << 16),
-                                       (uint32_t)Rb.w | ((uint32_t)Gb.w << 8) | ((uint32_t)Bb.w << 16));
-            *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = o;
+        ob = make_uint4(y2_pack3(Rb.x, Gb.x, Bb.x), y2_pack3(Rb.y, Gb.y, Bb.y), y2_pack3(Rb.z, Gb.z, Bb.z), y2_pack3(Rb.w, Gb.w, Bb.w));
+        if (lane < 16) *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = ob;
+        if (BX * 64 + 64 > w) {                                              // wave-uniform, rare: lanes beyond the right edge replicate column w - 1 (their loads were clamped to columns w-4 .. w-1)
+            if (!inX) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) *reinterpret_cast<uint4*>(&s_pix[(r0 + 4 * k) * LS + g4]) = make_uint4(o[k].w, o[k].w, o[k].w, o[k].w);
+                if (lane < 16) *reinterpret_cast<uint4*>(&s_pix[16 * LS + g4]) = make_uint4(ob.w, ob.w, ob.w, ob.w);
+            }
         }
         if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
         *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
@@ -540,25 +599,8 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
 
-    // ---- corner lattice (every 4th pixel, 17 x 5 points incl. the halo): Round6 / Round6P of the three channels at once (SWAR)
-    // and the five packed streams of y2_grad_pass
-    for (int idx = lane; idx < YK2_LATN; idx += 64) {
-        const int lr = idx / 17, lc = idx - lr * 17;
-        const uint32_t raw = s_pix[(lr * 4) * LS + lc * 4];
-        const uint32_t r6 = (raw & 0x00FCFCFCu) | ((raw >> 6) & 0x00030303u);                    // EncoderContext.cpp:3183
-        const uint32_t z = (raw & 0x007F7F7Fu) + 0x00010101u;
-        const uint32_t inc = (z ^ (raw & 0x00808080u)) | (((z & raw & 0x00808080u) >> 7) * 255u);   // min(v + 1, 255) per byte
-        const uint32_t p6 = (inc & 0x00FCFCFCu) | ((inc >> 6) & 0x00030303u);                    // EncoderContext.cpp:3202
-        s_lat[0 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C040C00u);
-        s_lat[1 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C050C01u);
-        s_lat[2 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C060C02u);
-        s_lat[3 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C010C00u);
-        s_lat[4 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C020C02u);
-    }
-    __syncthreads();
-
-    // ---- lane geometry: wave = macro-tile row `wave` of the block, lane = macroTile(q)*16 + cellY*4 + cellX ------------
-    const int q = lane >> 4, cell = lane & 15, cx = cell & 3, cy = cell >> 2;
+    // ---- lane geometry: wave = macro-tile row `wave` of the block, lane = macroTile(q)*16 + Morton(cellX, cellY) ------------
+    const int q = lane >> 4, cx = y2_cell_x(lane & 15), cy = y2_cell_y(lane & 15);
     const int bxCell = q * 16 + cx * 4, byCell = wave * 16 + cy * 4;          // cell origin inside the block
     const int gxCell = BX * 64 + bxCell, gyCell = BY * 64 + byCell;          // stripe-local pixels
     const int lcell = (cy * 4) * LS + bxCell;                                // strip-local LDS word of the cell origin
@@ -577,19 +619,41 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     {
         // S' is linear in x inside any tile, so |c(x-1)-2c(x)+c(x+1)| <= 4*rejectFactor+1 is necessary for acceptance of every
         // tile containing the three pixels (see tests/csrc/yk_encode_v1.hip).  Row 0 of the cell is tested: six tests already leave a cell of
-        // noise alive with probability < 1e-7, a second row only costs the other content instructions.
+        // noise alive with probability < 1e-7, a second row only costs the other content instructions.  Packed: channels 0 | 2 of a pixel
+        // in the halves of a register, channel 1 of two neighbouring pixels; d + lim as u16 exceeds 2 lim when |d| > lim.
         bool dead = !mtIn;
         {
             const int lim = 4 * P.rejectFactor + 1;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int c0 = y2_byte(pw[0], ch), c1 = y2_byte(pw[1], ch), c2 = y2_byte(pw[2], ch), c3 = y2_byte(pw[3], ch);
-                dead |= (abs(c0 - 2 * c1 + c2) > lim) | (abs(c1 - 2 * c2 + c3) > lim);
-            }
+            const y2u2 rb0 = y2_u2(pw[0] & 0x00FF00FFu), rb1 = y2_u2(pw[1] & 0x00FF00FFu), rb2 = y2_u2(pw[2] & 0x00FF00FFu), rb3 = y2_u2(pw[3] & 0x00FF00FFu);
+            const y2u2 ga = y2_u2(__builtin_amdgcn_perm(pw[1], pw[0], 0x0C050C01u)), gb = y2_u2(__builtin_amdgcn_perm(pw[2], pw[1], 0x0C050C01u)),
+                       gc = y2_u2(__builtin_amdgcn_perm(pw[3], pw[2], 0x0C050C01u));
+            const y2u2 l2 = y2_splat(lim);
+            const y2u2 u1 = rb0 + rb2 - rb1 - rb1 + l2, u2 = rb1 + rb3 - rb2 - rb2 + l2, ug = ga + gc - gb - gb + l2;
+            const y2u2 um = __builtin_elementwise_max(__builtin_elementwise_max(u1, u2), ug);
+            dead |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(um, y2_splat(2 * lim))) != 0u;
         }
         const unsigned long long deadLanes = __ballot(dead);
+        YK2_STAT(75, 1); YK2_STAT(76, ~deadLanes == 0ULL ? 1 : 0); YK2_STAT(77, __popcll(deadLanes));
         const bool stripInside = (BX * 64 + 64 <= w) && (BY * 64 + wave * 16 + 16 <= h);     // no tile of the strip crosses the image's edge
         if (~deadLanes != 0ULL && !(P.ablate & 2)) {
+            // corner lattice (every 4th pixel, 17 x 5 points incl. the halo): Round6 / Round6P of the three channels at once (SWAR)
+            // and the five packed streams of y2_grad_pass
+            auto latticePoint = [&](const int idx) {
+                const int lr = (idx * 241) >> 12, lc = idx - lr * 17;        // idx / 17 for idx < 85
+                const uint32_t raw = s_pix[(lr * 4) * LS + lc * 4];
+                const uint32_t r6 = (raw & 0x00FCFCFCu) | ((raw >> 6) & 0x00030303u);                    // EncoderContext.cpp:3183
+                const uint32_t z = (raw & 0x007F7F7Fu) + 0x00010101u;
+                const uint32_t inc = (z ^ (raw & 0x00808080u)) | (((z & raw & 0x00808080u) >> 7) * 255u);   // min(v + 1, 255) per byte
+                const uint32_t p6 = (inc & 0x00FCFCFCu) | ((inc >> 6) & 0x00030303u);                    // EncoderContext.cpp:3202
+                s_lat[0 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C040C00u);
+                s_lat[1 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C050C01u);
+                s_lat[2 * YK2_LATN + idx] = __builtin_amdgcn_perm(r6, raw, 0x0C060C02u);
+                s_lat[3 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C010C00u);
+                s_lat[4 * YK2_LATN + idx] = __builtin_amdgcn_perm(p6, p6, 0x0C020C02u);
+            };
+            latticePoint(lane);
+            if (lane < YK2_LATN - 64) latticePoint(lane + 64);
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
             y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
@@ -606,7 +670,11 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     }
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
-    if (cell == 0 && mtIn) coverageP[mtIdx] = (uint16_t)((cov >> (q * 16)) & 0xFFFFULL);       // bit = cellY*4 + cellX
+    {   // coverage word of the macro-tile: bit = cellY*4 + cellX (row-major: Morton index with its two middle bits exchanged)
+        const unsigned long long t = ((cov >> 2) ^ cov) & 0x0C0C0C0C0C0C0C0CULL;
+        const unsigned long long covRM = cov ^ t ^ (t << 2);
+        if ((lane & 15) == 0 && mtIn) coverageP[mtIdx] = (uint16_t)((covRM >> (q * 16)) & 0xFFFFULL);
+    }
 
     // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
     // strip's tiles into whole bytes of the block's words except 16x16 (4 bits per strip), which is OR-ed into a pre-zeroed map.
@@ -633,7 +701,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     }
     YK2_PROBE(3);
-    // ---- a10-a13: range quantiser; an 8x8 tile = the four lanes {l, l^1, l^4, l^5} ----------------------------------
+    // ---- a10-a13: range quantiser; an 8x8 tile = the quad of lanes {l & ~3 .. l | 3} -----------------------------------
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
     if (boundsP) {
         const int b0 = boundsP[0], b1 = boundsP[1], b2 = boundsP[2], b3 = boundsP[3];
@@ -648,21 +716,17 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const bool part = tileIn && tgx >= cxB && tgx < cxB + cw && tgy >= cyB && tgy < cyB + chh && (tgx + 8 <= cw) && (tgy + 8 <= chh);
     const bool keepMT = (keepP == nullptr) || discard || (mtIn && keepP[mtIdx] != 0);
     const bool tileLive = part && keepMT;
-    const int l00 = lane - cyl * 4 - cxl;                                    // lane of the tile's top-left cell
-    // uncovered quadrants of the lane's 8x8 tile (top-left, top-right, bottom-left, bottom-right), from the coverage mask on the scalar unit
-    constexpr unsigned long long O22 = y2_origin<2, 2>();
-    const unsigned long long ncov = ~cov;
-    const bool v00 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>(ncov & O22));
-    const bool v10 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 1) & O22));
-    const bool v01 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 4) & O22));
-    const bool v11 = __builtin_amdgcn_inverse_ballot_w64(y2_spread<2, 2>((ncov >> 5) & O22));
-    const bool valid = tileLive && __builtin_amdgcn_inverse_ballot_w64(ncov);   // valid = mipmapMask && !smoothMap (Plane.cpp:527)
-    const int nTop = (int)v00 + (int)v10, nBot = (int)v01 + (int)v11;
-    const int valueCount = tileLive ? 16 * (nTop + nBot) : 0;
+    const int l00 = lane & ~3;                                               // lane of the tile's top-left cell
+    // uncovered quadrants of the lane's 8x8 tile: bits 0..3 = top-left, top-right, bottom-left, bottom-right (the quad's lanes in order)
+    const uint32_t quadN = (uint32_t)((~cov) >> l00) & 15u;
+    const int v00 = (int)(quadN & 1u), v01 = (int)((quadN >> 2) & 1u);
+    const bool valid = tileLive && ((quadN >> (lane & 3)) & 1u);              // valid = mipmapMask && !smoothMap (Plane.cpp:527)
+    const int nTop = __popc(quadN & 3u), nBot = __popc(quadN >> 2);
     const int tileIdx = (tgyl >> 3) * P.tilesW + (tgx >> 3);
     const size_t T8 = (size_t)P.tilesW * P.tilesH;
-    const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the wave (0..15)
-    const bool writer = (cxl == 0) && (cyl == 0) && tileIn;                  // one lane per tile writes count / def
+    const int tw = lane >> 2;                                                // tile index inside the wave (0..15)
+    const bool writer = ((lane & 3) == 0) && tileIn;                         // one lane per tile writes count / def
+    const unsigned long long validMask = __ballot(valid);
 
     // ---- first level of the stream compaction's scan, fused: nibbles and coded tiles per block of 1024 tiles (row-major tile
     // order = LeftRightOrder).  The counts are the same for the three planes.  A strip holds two runs of 8 consecutive tiles;
@@ -690,233 +754,284 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
     }
 
-    if (__ballot(valid) == 0ULL || (P.ablate & 1)) {
+    YK2_STAT(70, validMask != 0ULL ? 1 : 0); YK2_STAT(74, __popcll(validMask));
+    if (validMask == 0ULL || (P.ablate & 1)) {
         if (writer) {
 #pragma unroll
             for (int p = 0; p < 3; p++) tileCountP[p * T8 + tileIdx] = 0;
         }
     } else {
-        uint32_t* lut = &s_lut[tw][0];
+        uint32_t* lut = &s_lut[WANT_DST ? tw : 0][0];
         // curve constants for buildLut (test-only reconstruction); fetched here, off the path of the strip's pixel loads
         if (WANT_DST) {
             s_curve[lane >> 4][lane & 15] = c_curve2[lane >> 4][lane & 15];
             if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
         }
-#if YK2_QPOL != 0
-        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.qtab, 0, YK2_QNR * YK2_QROWS * 16, 0x00020000);
-#endif
-        const int j4 = cyl * 2 + cxl;                                        // lane index inside its tile
+        const int j4 = lane & 3;                                             // lane index inside its tile (cellY&1)*2 + (cellX&1)
         uint32_t slotOff[4];                                                 // byte offset of the lane's four nibble rows inside the plane's slot array
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int yIn = cyl * 4 + r;
-            const int pos = (yIn < 4) ? (yIn * 4 * nTop + (cxl ? 4 * (int)v00 : 0))
-                                      : (16 * nTop + (yIn - 4) * 4 * nBot + (cxl ? 4 * (int)v01 : 0));
+            const int pos = (yIn < 4) ? (yIn * 4 * nTop + (cxl ? 4 * v00 : 0))
+                                      : (16 * nTop + (yIn - 4) * 4 * nBot + (cxl ? 4 * v01 : 0));
             slotOff[r] = (uint32_t)tileIdx * (uint32_t)YK_SLOT + (uint32_t)(pos >> 1);
         }
-        for (int p = 0; p < 3; p++) {
-            // Plane::GetMinMax_Y over the tile (Plane.cpp:489-587)
-            int mn = 99999999, mx = -99999999;
+        // ---- Plane::GetMinMax_Y over the tile (Plane.cpp:489-587), the three planes at once: channels 0 | 2 of a pixel in the halves of a
+        // register, channel 1 of two pixels; lanes without valid pixels carry the neutral elements; the tile's value over its quad by DPP.
+        int tmn[3], tmx[3];
+        {
+            y2u2 mnRB = y2_splat(0xFFFF), mxRB = y2_splat(0), mnG = y2_splat(0xFFFF), mxG = y2_splat(0);
             if (valid) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) { const int v = y2_byte(pw[k], p); mn = min(mn, v); mx = max(mx, v); }
+                for (int k = 0; k < 16; k += 2) {
+                    const y2u2 a = y2_u2(pw[k] & 0x00FF00FFu), b = y2_u2(pw[k + 1] & 0x00FF00FFu), g = y2_u2(__builtin_amdgcn_perm(pw[k + 1], pw[k], 0x0C050C01u));
+                    if (k == 0) { mnRB = __builtin_elementwise_min(a, b); mxRB = __builtin_elementwise_max(a, b); mnG = g; mxG = g; }
+                    else {
+                        mnRB = __builtin_elementwise_min(__builtin_elementwise_min(mnRB, a), b); mxRB = __builtin_elementwise_max(__builtin_elementwise_max(mxRB, a), b);
+                        mnG = __builtin_elementwise_min(mnG, g); mxG = __builtin_elementwise_max(mxG, g);
+                    }
+                }
             }
-            mn = min(mn, y2_lane_xor1(mn)); mx = max(mx, y2_lane_xor1(mx));
-            mn = min(mn, y2_lane_xor4(mn)); mx = max(mx, y2_lane_xor4(mx));
-            if (mn == 99999999) { mn = 0; mx = 0; }
-            // DynamicTile::buildTable (:625-699)
+            tmn[0] = (int)mnRB.x; tmn[2] = (int)mnRB.y; tmx[0] = (int)mxRB.x; tmx[2] = (int)mxRB.y;
+            tmn[1] = min((int)mnG.x, (int)mnG.y); tmx[1] = max((int)mxG.x, (int)mxG.y);
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                tmn[p] = min(tmn[p], y2_quad<Y2_QUAD_X>(tmn[p])); tmx[p] = max(tmx[p], y2_quad<Y2_QUAD_X>(tmx[p]));
+                tmn[p] = min(tmn[p], y2_quad<Y2_QUAD_Y>(tmn[p])); tmx[p] = max(tmx[p], y2_quad<Y2_QUAD_Y>(tmx[p]));
+            }
+        }
+        // ---- DynamicTile::buildTable's integer part (:625-661) from the tile-definition table: the three planes' entries in one round trip
+        const uint32_t* const defTab = reinterpret_cast<const uint32_t*>(P.qtab + YK2_QBYTES + YK2_RCPBYTES);
+        uint32_t tdef[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int none = tmn[p] > 255;                                   // no valid pixel in the tile: (0, 0) (Plane.cpp:583-584)
+            const int mn = none ? 0 : tmn[p], mx = none ? 0 : tmx[p];
             const int min_ = min(mn, 224);
-            int diff = mx - min_; if (diff < 16) diff = 16;
-            const int base = (min_ * 63 + 112) / 224;
-            const int BN = (base * 224) / 63;
-            const int d8 = max(diff, 32);
-            const int scale = 223 - BN;
-            const int dnum = (d8 - 32) * 127 + (scale - 1);                  // see tests/csrc/yk_encode_v1.hip / yk_selftest 1
-            const int dist = (scale < 0) ? -dnum : __float2int_rz(((float)dnum + 0.5f) * __builtin_amdgcn_rcpf((float)scale));
-            const int rangeDecode = (dist * scale) / 127 + 32;
-            // The tile's six LUTs (4-bit: 16 entries + three quarter midpoints, 3-bit: 8 entries; stored << 8) in LDS.  Only the
-            // exact-order fallback and the test-only reconstruction (wantDst) read them: the per-pixel work goes through the
-            // quantiser table below.  Lane j4 of the tile builds entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit).
-            auto buildLut = [&]() {
-                const float Rf = (float)rangeDecode, BNf = (float)BN;
+            const int d8 = max(mx - min_, 32);
+            tdef[p] = defTab[(uint32_t)(min_ * YK2_DEFN1 + d8 - 32)];        // unsigned: scalar base + 32-bit lane offset
+            s_range[p * 64 + lane] = (uint32_t)mn | ((uint32_t)mx << 8);        // min | max << 8 of the tile's valid pixels, for the tie check (rare): parked in LDS
+        }
+        // the quantiser table's rows start 256 rows before the table (the row base of the definition table is biased by +256)
+        const uint8_t* const qrows = P.qtab - (size_t)256 * 16;
 #pragma unroll
-                for (int m = 0; m < 3; m++) {
-                    uint32_t L[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 4 + k], Rf)));
-                    *reinterpret_cast<uint4*>(&lut[m * 20 + j4 * 4]) = make_uint4(L[0] << 8, L[1] << 8, L[2] << 8, L[3] << 8);
-                }
-#pragma unroll
-                for (int m = 3; m < 6; m++) {
-                    uint32_t L[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++)
-                        L[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf)));
-                    *reinterpret_cast<uint2*>(&lut[60 + (m - 3) * 8 + j4 * 2]) = make_uint2(L[0] << 8, L[1] << 8);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-
-            // ---- nearest LUT entry per pixel and mode: ONE 12-byte row of the quantiser table (yk_qtab_kernel).  Every LUT is
+        for (int p = 0; p < 3; p++) {
+            // ---- nearest LUT entry per pixel and mode: ONE 16-byte row of the quantiser table (yk_qtab_kernel).  Every LUT is
             // BN + K[rangeDecode][mode][i] (the float add never carries into the integer part: checked for every (min, max) by
             // yk_selftest 3), so index and minDiff of a pixel depend only on rangeDecode and v - BN.  The table (0.9 MB) lives in
             // L2 and, for the few rangeDecode values a strip meets, in the CU's vector cache.
             // The reference adds the 64 exact terms minDiff/v SEQUENTIALLY in float (:885) and, walking the modes in order, keeps
             // mode m when err_m <= best (:897).  Any summation order of n <= 64 non-negative floats is within gamma_63 = 3.76e-6
             // (relative) of the exact sum and md*rcp(v) is within 2.5e-7 of the correctly rounded quotient, so a screening sum T
-            // (tree order, fast reciprocal) differs from the reference's sum by < 8e-6 relative.  Each of the reference's
+            // (tree order, reciprocal) differs from the reference's sum by < 8e-6 relative.  Each of the reference's
             // comparisons is therefore decided with certainty when the two sums are separated by 2e-5, or tie exactly with
             // identical per-pixel minDiffs (then the reference's sums are identical too: the later mode wins), or are both
             // exactly 0 (all terms 0).  Any other case (rare) flags the tile for exact re-summation in the reference's order.
-            const uint32_t qrow = (uint32_t)(((rangeDecode - YK2_QR0) * YK2_QROWS + 2 - BN) * 16);   // byte offset of the row of v = 0, modulo 2^32 (rows of the tile's own values, v >= BN - 2, are never negative)
+            const uint32_t qrow16 = (tdef[p] & 0xFFFFu) << 4;               // byte offset of the row of v = 0 behind qrows
             float sm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            uint32_t iw[16];                                                 // index nibbles of the six modes, per pixel
             if (valid && !(P.ablate & 4)) {
+                // A rolling window of YK2_WIN rows in flight (a row is four registers; all sixteen at once do not fit next to the pixels);
+                // the index words wait in LDS (word = pixel * 64 + lane: conflict-free) until the mode is chosen.
+                uint4 win[YK2_WIN]; float rvw[YK2_RVWIN];
+                auto issueRow = [&](const int k, uint4& row) {
+                    const uint32_t v4 = y2_byte_x4(pw[k], p);                    // 4 * value: LDS offset of its reciprocal, a quarter of its row offset
+                    row = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + qrow16));
+                };
+                // the reciprocal of the pixel value (a table: v_rcp_f32 is a quarter-rate op, 16 per plane add up); its LDS round trip is short: a small window of its own
+                auto issueRcp = [&](const int k, float& rv) { rv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_rcp) + y2_byte_x4(pw[k], p)); };
+#pragma unroll
+                for (int k = 0; k < YK2_WIN; k++) issueRow(k, win[k]);
+#pragma unroll
+                for (int k = 0; k < YK2_RVWIN; k++) issueRcp(k, rvw[k]);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const uint32_t v = (uint32_t)y2_byte(pw[k], p);
-#if YK2_QPOL == 0
-                    const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
-                    const uint32_t m03 = row[0], m45 = row[1];
-                    iw[k] = row[2];
-#else
-                    const y2u3 row = __builtin_amdgcn_raw_buffer_load_b96(qrsrc, qrow + v * 16u, 0, YK2_QPOL - 1);
-                    const uint32_t m03 = row.x, m45 = row.y;
-                    iw[k] = row.z;
-#endif
-                    const float rv = s_rcp[v];                                   // a table: v_rcp_f32 is a quarter-rate op, 16 per plane add up
-                    sm[0] = __fmaf_rn((float)(m03 & 255u), rv, sm[0]);
-                    sm[1] = __fmaf_rn((float)((m03 >> 8) & 255u), rv, sm[1]);
-                    sm[2] = __fmaf_rn((float)((m03 >> 16) & 255u), rv, sm[2]);
-                    sm[3] = __fmaf_rn((float)(m03 >> 24), rv, sm[3]);
-                    sm[4] = __fmaf_rn((float)(m45 & 255u), rv, sm[4]);
-                    sm[5] = __fmaf_rn((float)((m45 >> 8) & 255u), rv, sm[5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint4 row = win[k % YK2_WIN]; const float rv = rvw[k % YK2_RVWIN];
+                    // sum += minDiff * (1 / v): the f16 halves of the row go straight into the multiply-add (one rounding, like __fmaf_rn on the converted value)
+                    if (!MODE3) { y2_fma_lo(sm[0], row.x, rv); y2_fma_hi(sm[1], row.x, rv); y2_fma_lo(sm[2], row.y, rv); }
+                    y2_fma_hi(sm[3], row.y, rv); y2_fma_lo(sm[4], row.z, rv); y2_fma_hi(sm[5], row.z, rv);
+                    s_iw[k * 64 + lane] = row.w;
+                    if (k + YK2_WIN < 16) issueRow(k + YK2_WIN, win[k % YK2_WIN]);
+                    if (k + YK2_RVWIN < 16) issueRcp(k + YK2_RVWIN, rvw[k % YK2_RVWIN]);
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) iw[k] = 0;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            int bestMode = -1; float bestT = 0.0f;
+            // the tile's sums over its quad; mode selection: the reference keeps mode m when err_m <= best, i.e. the running minimum with
+            // the later mode on ties; `near` = the two sums are neither surely ordered nor exactly equal
+            int bestMode = kStart; float bestT = 0.0f;
             bool amb = false;
             uint32_t ties = 0;                                               // bit m: mode m tied with the best so far (bits 8+3m..: that mode)
 #pragma unroll
-            for (int m = 0; m < 6; m++) {
-                if (m >= P.startMode) {
-                    float t = sm[m];
-                    t = __fadd_rn(t, y2_lane_xor1(t)); t = __fadd_rn(t, y2_lane_xor4(t));
-                    bool take;
-                    if (bestMode < 0) take = true;
-                    else if (__fmul_rn(t, 1.00002f) < bestT) take = true;                        // surely smaller
-                    else if (__fmul_rn(bestT, 1.00002f) < t) take = false;                       // surely larger
-                    else if (t == bestT) {
-                        take = true;                                                             // both exactly zero, or identical minDiffs: checked below
-                        if (t != 0.0f) ties |= (1u << m) | ((uint32_t)bestMode << (8 + 3 * m));
-                    } else { take = t <= bestT; amb = true; }
-                    if (take) { bestMode = m; bestT = t; }
-                }
+            for (int m = kStart; m < 6; m++) {
+                float t = sm[m];
+                t = __fadd_rn(t, y2_quad<Y2_QUAD_X>(t)); t = __fadd_rn(t, y2_quad<Y2_QUAD_Y>(t));
+                if (m == kStart) { bestT = t; continue; }
+                const float lo = fminf(t, bestT), hi = fmaxf(t, bestT);
+                const bool eq = (t == bestT);
+                amb |= !eq && !(__fmul_rn(lo, 1.00002f) < hi);                // not surely ordered
+                if (eq && t != 0.0f) ties |= (1u << m) | ((uint32_t)bestMode << (8 + 3 * m));   // both exactly zero needs no check
+                bestMode = (t <= bestT) ? m : bestMode;
+                bestT = lo;
             }
-            if (bestMode < 0) bestMode = 5;
-            // exact ties: the later mode wins when the two modes' minDiffs agree on every valid pixel of the tile (identical sums in
-            // the reference too); otherwise the tile is ambiguous.  Rare enough to re-read the rows (cache hits) instead of keeping them.
+            // exact ties: the later mode wins when the two modes' minDiffs agree on every valid pixel of the tile (identical sums in the
+            // reference too); otherwise the tile is ambiguous.  Flat tiles tie all the time (a smooth region next to a contour): instead of
+            // walking the pixels again, the rows of ALL values between the tile's minimum and maximum are compared (at most eight: two per lane
+            // of the quad, every mode pair at once by xor); a wider range, or a row in which the two modes differ, sends the tile to the exact path.
             if (__ballot(ties != 0u && tileLive) != 0ULL) {
-                uint32_t differ = 0;
-                if (valid) {
+                YK2_STAT(73, 1);
+                const uint32_t tr = s_range[p * 64 + lane];
+                const uint32_t mn = tr & 255u, mx = tr >> 8;
+                const uint32_t va = min(mn + (uint32_t)j4, mx), vb = min(mn + 4u + (uint32_t)j4, mx);
+                const uint4 ra = *reinterpret_cast<const uint4*>(qrows + (size_t)((va << 4) + qrow16));
+                const uint4 rb = *reinterpret_cast<const uint4*>(qrows + (size_t)((vb << 4) + qrow16));
+                // minDiffs as f16 halves: x = modes 0|1, y = 2|3, z = 4|5; a half of an accumulator is non-zero when its pair of modes differs in some row
+                const uint32_t rxa = __builtin_amdgcn_alignbit(ra.x, ra.x, 16), rya = __builtin_amdgcn_alignbit(ra.y, ra.y, 16), rza = __builtin_amdgcn_alignbit(ra.z, ra.z, 16);
+                const uint32_t rxb = __builtin_amdgcn_alignbit(rb.x, rb.x, 16), ryb = __builtin_amdgcn_alignbit(rb.y, rb.y, 16), rzb = __builtin_amdgcn_alignbit(rb.z, rb.z, 16);
+                uint32_t acc[9] = { (ra.x ^ rxa) | (rb.x ^ rxb),                 // (0,1)
+                                    (ra.y ^ rya) | (rb.y ^ ryb),                 // (2,3)
+                                    (ra.z ^ rza) | (rb.z ^ rzb),                 // (4,5)
+                                    (ra.x ^ ra.y) | (rb.x ^ rb.y),               // low (0,2), high (1,3)
+                                    (ra.x ^ ra.z) | (rb.x ^ rb.z),               // low (0,4), high (1,5)
+                                    (ra.y ^ ra.z) | (rb.y ^ rb.z),               // low (2,4), high (3,5)
+                                    (ra.x ^ rya) | (rb.x ^ ryb),                 // low (0,3), high (1,2)
+                                    (ra.x ^ rza) | (rb.x ^ rzb),                 // low (0,5), high (1,4)
+                                    (ra.y ^ rza) | (rb.y ^ rzb) };               // low (2,5), high (3,4)
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const uint32_t v = (uint32_t)y2_byte(pw[k], p);
-                        const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + v * 16u));
-                        const unsigned long long X = ((unsigned long long)row[1] << 32) | row[0];
+                for (int i = 0; i < 9; i++) { acc[i] |= (uint32_t)y2_quad<Y2_QUAD_X>((int)acc[i]); acc[i] |= (uint32_t)y2_quad<Y2_QUAD_Y>((int)acc[i]); }
+                bool differ = (mx - mn) > 7u;
+                auto pairDiffers = [&](const int i, const int j) -> bool {       // i < j
+                    const int lo = i < j ? i : j, hi = i < j ? j : i;
+                    if (lo == 0 && hi == 1) return (acc[0] & 0xFFFFu) != 0u;
+                    if (lo == 2 && hi == 3) return (acc[1] & 0xFFFFu) != 0u;
+                    if (lo == 4 && hi == 5) return (acc[2] & 0xFFFFu) != 0u;
+                    if (lo == 0 && hi == 2) return (acc[3] & 0xFFFFu) != 0u;
+                    if (lo == 1 && hi == 3) return (acc[3] >> 16) != 0u;
+                    if (lo == 0 && hi == 4) return (acc[4] & 0xFFFFu) != 0u;
+                    if (lo == 1 && hi == 5) return (acc[4] >> 16) != 0u;
+                    if (lo == 2 && hi == 4) return (acc[5] & 0xFFFFu) != 0u;
+                    if (lo == 3 && hi == 5) return (acc[5] >> 16) != 0u;
+                    if (lo == 0 && hi == 3) return (acc[6] & 0xFFFFu) != 0u;
+                    if (lo == 1 && hi == 2) return (acc[6] >> 16) != 0u;
+                    if (lo == 0 && hi == 5) return (acc[7] & 0xFFFFu) != 0u;
+                    if (lo == 1 && hi == 4) return (acc[7] >> 16) != 0u;
+                    if (lo == 2 && hi == 5) return (acc[8] & 0xFFFFu) != 0u;
+                    return (acc[8] >> 16) != 0u;                                 // (3,4)
+                };
 #pragma unroll
-                        for (int m = 1; m < 6; m++) {
-                            const uint32_t b = (ties >> (8 + 3 * m)) & 7u;
-                            differ |= ((((uint32_t)(X >> (8 * m)) ^ (uint32_t)(X >> (8 * b))) & 255u) ? 1u : 0u) << m;
-                        }
-                    }
+                for (int m = kStart + 1; m < 6; m++) {
+                    const uint32_t fb = ((ties >> m) & 1u) ? ((ties >> (8 + 3 * m)) & 7u) : 7u;   // the mode that mode m tied with, 7 = none
+#pragma unroll
+                    for (int b2 = kStart; b2 < m; b2++) differ |= (fb == (uint32_t)b2) && pairDiffers(b2, m);
                 }
-                differ &= ties;
-                if ((__ballot(differ != 0u) & (0x33ULL << l00)) != 0ULL) amb = true;     // the tile's four lanes are active together
+                if (ties != 0u && differ) amb = true;
             }
             uint32_t cLo = 0, cHi = 0;
-            {                                                                // the lane's 16 index nibbles of the best mode, pixel 0 lowest
+            if (valid) {                                                     // the lane's 16 index nibbles of the best mode, pixel 0 lowest
                 const uint32_t sh = 4u * (uint32_t)bestMode;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     // pixel k's index nibble enters at the top and shifts down: after 8 pixels pixel 0 sits lowest
-                    const uint32_t code = iw[k] >> sh;
+                    const uint32_t code = s_iw[k * 64 + lane] >> sh;
                     if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
                 }
             }
             if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
             unsigned long long ambMask = __ballot(amb && tileLive);
+            YK2_STAT(72, __popcll(ambMask) / 4); YK2_STAT(71, ambMask != 0ULL ? 1 : 0);
 #ifdef YK2_TIMING
             if (lane == 0 && unit < 65536 && ambMask) { g_y2_times[(size_t)unit * 16 + 10] += (unsigned long long)__popcll(ambMask) / 4; g_y2_times[(size_t)unit * 16 + 11] += 1; }
 #endif
-            if (WANT_DST) buildLut();
-            while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
-                const int al = __ffsll((long long)ambMask) - 1;              // a lane of the tile
-                const int ac = al & 15;
-                const int a00 = al - ((ac >> 2) & 1) * 4 - (ac & 1);        // top-left lane of that tile
-                ambMask &= ~(0x33ULL << a00);
-                if (l00 == a00) {                                            // the four lanes of the tile publish their exact terms in pixel order
+            if (WANT_DST) {
+                // The tile's six LUTs (4-bit: 16 entries, 3-bit: 8 entries; stored << 8) in LDS, built the reference's way (:662-696); only the
+                // test-only reconstruction reads them.  Lane j4 of the tile builds entries 4*j4..4*j4+3 (4-bit) and 2*j4, 2*j4+1 (3-bit).
+                const int rowBase = (int)(tdef[p] & 0xFFFFu) - 256 - 2;      // (R - 32) * 258 - BN
+                const int base = (int)((tdef[p] >> 16) & 127u);
+                const int BN = (base * 224) / 63;
+                const int rangeDecode = (rowBase + BN) / YK2_QROWS + YK2_QR0;
+                const float Rf = (float)rangeDecode, BNf = (float)BN;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {                            // four rows in flight at a time: this path is rare, registers matter more
-                        uint32_t m03[4], m45[4];
+                for (int m = 0; m < 3; m++) {
+                    uint32_t Lq[4];
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            m03[i] = 0; m45[i] = 0;
-                            if (valid) {
-                                const uint32_t* row = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + (uint32_t)y2_byte(pw[r * 4 + i], p) * 16u));
-                                m03[i] = row[0]; m45[i] = row[1];
-                            }
-                        }
+                    for (int k = 0; k < 4; k++)
+                        Lq[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 4 + k], Rf)));
+                    *reinterpret_cast<uint4*>(&lut[m * 20 + j4 * 4]) = make_uint4(Lq[0] << 8, Lq[1] << 8, Lq[2] << 8, Lq[3] << 8);
+                }
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const uint32_t v = (uint32_t)y2_byte(pw[r * 4 + i], p);
-                            // minDiff / v as the reference's divss (:885): correctly rounded reciprocal + one correction step (yk_selftest 0);
-                            // a skipped pixel (covered, masked or v == 0) contributes +0, which leaves a float sum unchanged
-                            const float fv = (float)v, rr = valid ? s_rcp[v] : 0.0f;
-                            float* dst = &s_chain[0][(cyl * 4 + r) * 8 + cxl * 4 + i];
-                            dst[0 * 68] = yk_div_exact((float)(m03[i] & 255u), fv, rr);
-                            dst[1 * 68] = yk_div_exact((float)((m03[i] >> 8) & 255u), fv, rr);
-                            dst[2 * 68] = yk_div_exact((float)((m03[i] >> 16) & 255u), fv, rr);
-                            dst[3 * 68] = yk_div_exact((float)(m03[i] >> 24), fv, rr);
-                            dst[4 * 68] = yk_div_exact((float)(m45[i] & 255u), fv, rr);
-                            dst[5 * 68] = yk_div_exact((float)((m45[i] >> 8) & 255u), fv, rr);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                for (int m = 3; m < 6; m++) {
+                    uint32_t Lq[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+                        Lq[k] = (uint32_t)__float2int_rz(__fadd_rn(BNf, __fmul_rn(s_curve[m][j4 * 2 + k], Rf)));
+                    *reinterpret_cast<uint2*>(&lut[60 + (m - 3) * 8 + j4 * 2]) = make_uint2(Lq[0] << 8, Lq[1] << 8);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane < 6 && lane >= P.startMode) {                       // errorDist += minDiff / v in row-major pixel order (:885)
-                    float s = 0.0f;
+            }
+            while (ambMask != 0ULL) {                                        // wave-uniform loop over the ambiguous tiles (rare)
+                // The whole wave re-sums ONE tile-plane in the reference's order: the tile's four lanes publish its 64 values, lane i takes
+                // pixel i (row-major in the tile): one row gather and six exact quotients per lane, then six lanes add the 64 terms of a mode
+                // one after the other.  One memory round trip per tile-plane (a lane walking its own sixteen pixels took sixteen).
+                const int a00 = (__ffsll((long long)ambMask) - 1) & ~3;      // top-left lane of that tile
+                ambMask &= ~(0xFULL << a00);
+                if (l00 == a00) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t kSel = 0x0C0C0000u | ((4u + (uint32_t)p) << 8) | (uint32_t)p;         // byte p of two words (p is unrolled: a constant)
+                        const uint32_t lo2 = __builtin_amdgcn_perm(pw[r * 4 + 1], pw[r * 4 + 0], kSel), hi2 = __builtin_amdgcn_perm(pw[r * 4 + 3], pw[r * 4 + 2], kSel);
+                        s_tile[(cyl * 4 + r) * 2 + cxl] = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+                    }
+                }
+                const uint32_t tq16 = (uint32_t)__builtin_amdgcn_readlane((int)qrow16, a00), tqn = (uint32_t)__builtin_amdgcn_readlane((int)quadN, a00);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    const uint32_t v = (uint32_t)reinterpret_cast<const uint8_t*>(s_tile)[lane];
+                    const bool pv = ((tqn >> (((lane >> 5) << 1) | ((lane >> 2) & 1))) & 1u) != 0u;      // the pixel's quadrant is uncovered (the tile is live)
+                    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+                    if (pv) rw = *reinterpret_cast<const uint4*>(qrows + (size_t)((v << 4) + tq16));
+                    // minDiff / v as the reference's divss (:885): correctly rounded reciprocal + one correction step (yk_selftest 0);
+                    // a skipped pixel (covered or v == 0) contributes +0, which leaves a float sum unchanged
+                    const float fv = (float)v, rr = pv ? s_rcp[v] : 0.0f;
+                    const y2h2 h01 = __builtin_bit_cast(y2h2, rw.x), h23 = __builtin_bit_cast(y2h2, rw.y), h45 = __builtin_bit_cast(y2h2, rw.z);
+                    s_chain[0][lane] = yk_div_exact((float)h01.x, fv, rr);
+                    s_chain[1][lane] = yk_div_exact((float)h01.y, fv, rr);
+                    s_chain[2][lane] = yk_div_exact((float)h23.x, fv, rr);
+                    s_chain[3][lane] = yk_div_exact((float)h23.y, fv, rr);
+                    s_chain[4][lane] = yk_div_exact((float)h45.x, fv, rr);
+                    s_chain[5][lane] = yk_div_exact((float)h45.y, fv, rr);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 6 && lane >= kStart) {                            // errorDist += minDiff / v in row-major pixel order (:885)
+                    float sacc = 0.0f;
                     const float4* cp = reinterpret_cast<const float4*>(&s_chain[lane][0]);
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         const float4 a = cp[k];
-                        s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, a.x), a.y), a.z), a.w);
+                        sacc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sacc, a.x), a.y), a.z), a.w);
                     }
-                    s_err[lane] = s;
+                    s_err[lane] = sacc;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (l00 == a00) {                                            // last mode whose error is <= the best so far (:897-905)
                     bestMode = -1; float bestErr = 99999999.0f;
-                    for (int m = P.startMode; m < 6; m++) {
+                    for (int m = kStart; m < 6; m++) {
                         const float e = s_err[m];
                         if (e <= bestErr) { bestErr = e; bestMode = m; }
                     }
-                    const uint32_t sh = 4u * (uint32_t)bestMode;             // the index words are read again: they are not kept for this rare path
+                    if (valid) {
+                        const uint32_t sh = 4u * (uint32_t)bestMode;
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        uint32_t code = 0;
-                        if (valid) code = reinterpret_cast<const uint32_t*>(P.qtab + (size_t)(qrow + (uint32_t)y2_byte(pw[k], p) * 16u))[2] >> sh;
-                        if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
+                        for (int k = 0; k < 16; k++) {
+                            const uint32_t code = s_iw[k * 64 + lane] >> sh;
+                            if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -941,9 +1056,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 }
             }
             if (writer) {
-                tileCountP[p * T8 + tileIdx] = (uint8_t)valueCount;
+                // scalar base + 32-bit lane offset, formed next to the stores (hoisted 64-bit addresses live across the planes and spill)
+                uint32_t ti = (uint32_t)tileIdx;
+                asm volatile("" : "+v"(ti));
+                (tileCountP + (size_t)p * T8)[ti] = (uint8_t)(tileLive ? 16 * (nTop + nBot) : 0);
                 // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
-                tileDefP[p * T8 + tileIdx] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (((uint32_t)dist & 255u) << 7) | ((uint32_t)base & 255u));
+                (tileDefP + (size_t)p * T8)[ti] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (tdef[p] >> 16));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -951,7 +1069,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     YK2_PROBE(4);
 }
 
-// one quantiser table per device and process, built on first use
+// one set of tables per device and process, built on first use: quantiser rows | reciprocals | tile definitions
 static uint8_t* g_qtab[64] = {};
 static std::mutex g_qtabMu;
 int yk_qtab_get(yk_ctx* c) {
@@ -959,13 +1077,17 @@ int yk_qtab_get(yk_ctx* c) {
     if (c->device < 0 || c->device >= 64) return yk_fail(c, YK_ERR_BAD_ARG, "device index");
     if (!g_qtab[c->device]) {
         uint8_t* t = nullptr;
-        YK_HIP(c, hipMalloc(&t, YK2_QBYTES + 256 * sizeof(float)));
+        // 4 KB in front: the kernel addresses the rows from 256 rows before the table (row bases are biased by +256)
+        YK_HIP(c, hipMalloc(&t, 4096 + YK2_TABBYTES));
+        YK_HIP(c, hipMemsetAsync(t, 0, 4096, c->stream));
+        t += 4096;
         hipLaunchKernelGGL(yk_qtab_kernel, dim3(YK2_QNR), dim3(320), 0, c->stream, reinterpret_cast<uint4*>(t));
         {   // behind the rows: RN(1 / v) for v = 1..255, [0] = 0 (a skipped term, :884); IEEE division on the host = __fdiv_rn
             float rcp[256]; rcp[0] = 0.0f;
             for (int v = 1; v < 256; v++) rcp[v] = 1.0f / (float)v;
             YK_HIP(c, hipMemcpyAsync(t + YK2_QBYTES, rcp, sizeof rcp, hipMemcpyHostToDevice, c->stream));
         }
+        hipLaunchKernelGGL(yk_deftab_kernel, dim3(225), dim3(YK2_DEFN1), 0, c->stream, reinterpret_cast<uint32_t*>(t + YK2_QBYTES + YK2_RCPBYTES));
         YK_HIP(c, hipGetLastError());
         YK_HIP(c, hipStreamSynchronize(c->stream));
         g_qtab[c->device] = t;
@@ -974,17 +1096,24 @@ int yk_qtab_get(yk_ctx* c) {
     return YK_OK;
 }
 void yk_selftest_qtab_launch(yk_ctx* c, int* mismatches) {
-    hipLaunchKernelGGL(yk_selftest_qtab_kernel, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(c->qtab), mismatches);
+    hipLaunchKernelGGL(yk_selftest_qtab_kernel, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(c->qtab),
+                       reinterpret_cast<const uint32_t*>(c->qtab + YK2_QBYTES + YK2_RCPBYTES), mismatches);
 }
 
 int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
     if (!P.qtab) return yk_fail(c, YK_ERR_STATE, "quantiser table missing");
+    if (P.startMode != 0 && P.startMode != 3) return yk_fail(c, YK_ERR_BAD_ARG, "startMode must be 0 or 3");
     const int nB = P.xBB64 * P.yBB64 * P.nFrames, group = 8 * YK2_RUN;
     // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
     YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
     dim3 grid(((nB + group - 1) / group) * group * 4);
-    if (P.wantDst) hipLaunchKernelGGL(yk_encode2_kernel<true>, grid, dim3(64), 0, c->stream, P);
-    else hipLaunchKernelGGL(yk_encode2_kernel<false>, grid, dim3(64), 0, c->stream, P);
+    if (P.wantDst) {
+        if (P.startMode) hipLaunchKernelGGL((yk_encode2_kernel<true, true>), grid, dim3(64), 0, c->stream, P);
+        else hipLaunchKernelGGL((yk_encode2_kernel<true, false>), grid, dim3(64), 0, c->stream, P);
+    } else {
+        if (P.startMode) hipLaunchKernelGGL((yk_encode2_kernel<false, true>), grid, dim3(64), 0, c->stream, P);
+        else hipLaunchKernelGGL((yk_encode2_kernel<false, false>), grid, dim3(64), 0, c->stream, P);
+    }
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
