@@ -89,7 +89,7 @@ template <int NX, int NY> __device__ __forceinline__ unsigned long long y2_sprea
     return m;
 }
 
-template <int SX, int SY>
+template <int SX, int SY, bool SMOOTH = false>
 __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy,
                                              const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes, const bool stripInside,
                                              const int gxCell, const int gyCell, const int w, const int h, const int rf,
@@ -108,6 +108,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     YK2_STAT(kPassId * 10 + 0, 1); YK2_STAT(kPassId * 10 + 8, __popcll(y2_spread<NX, NY>(viable)));
     const int loO = -256 * rf, hiO = 256 * rf + 255;
     const y2s2 loO2 = y2_splats(loO), hiO2 = y2_splats(hiO), loR2 = y2_splats(loO - 127), hiR2 = y2_splats(hiO - 127);
+
 
 #ifndef YK2_NO_COMPACT
     // ---- few viable cells (a strip whose larger tiles failed along an edge, the usual case next to contours): a pass over 64 lanes
@@ -266,6 +267,35 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     //    the four raw / Round6 variants accepts (on clean gradients the raw corners pass and two streams in five are never walked).
     constexpr bool kScreen = (NX * NY >= 4);
     constexpr unsigned kA = 0x07u, kP = 0x18u;
+    unsigned long long accept;
+    if (SMOOTH) {
+        // A strip without a single lane killed by the curvature test (smooth content): the screens below would only cost it instructions and
+        // two more dependent round trips through LDS and the scalar unit.  The raw / Round6 streams walk the whole tile at once; the Round6P
+        // streams only for tiles those four variants fail.
+        setup(0); setup(1); setup(2);
+        pixelRow(0, kA, true);
+        nextRow(0, kA); pixelRow(1, kA, false);
+        nextRow(1, kA); pixelRow(2, kA, false);
+        nextRow(2, kA); pixelRow(3, kA, false);
+        YK2_STAT(kPassId * 10 + 4, 1);
+        accept = viable & ~failA4(mnAll(), mxAll());
+        const unsigned long long rest = viable & ~accept;
+        if (rest != 0ULL) {
+            YK2_STAT(kPassId * 10 + 5, 1); YK2_STAT(90 + kPassId, __popcll(y2_spread<NX, NY>(rest)));
+            // a tile next to a contour usually fails these two variants in the first row of its cells already (its corners are off)
+            setup(3);
+            pixelRow(0, 0x08u, true);
+            const unsigned long long left = rest & ~failP2(mn[3], mx[3]);
+            if (left != 0ULL) {
+                setup(4);
+                pixelRow(0, 0x10u, true);
+                nextRow(0, kP); pixelRow(1, kP, false);
+                nextRow(1, kP); pixelRow(2, kP, false);
+                nextRow(2, kP); pixelRow(3, kP, false);
+                accept |= left & ~failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));
+            }
+        }
+    } else {
     int pRows;                                                           // rows the Round6P streams have walked so far
     if (kScreen) {
         setup(0); setup(3);
@@ -298,7 +328,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
     pixelRow(2, kA, false);
     nextRow(2, kA);
     pixelRow(3, kA, false);
-    unsigned long long accept = viable & ~failA4(mnAll(), mxAll());      // some raw / Round6 variant never failed (:3998)
+    accept = viable & ~failA4(mnAll(), mxAll());                         // some raw / Round6 variant never failed (:3998)
     const unsigned long long rest = viable & ~accept;
     if (rest != 0ULL) {                                                  // wave-uniform: the Round6P variants decide the remaining tiles
         YK2_STAT(kPassId * 10 + 5, 1); YK2_STAT(90 + kPassId, __popcll(y2_spread<NX, NY>(rest)));
@@ -315,6 +345,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         accept |= rest & ~failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));
     }
     (void)pRows;
+    }
     if (accept == 0ULL) return;
     YK2_STAT(kPassId * 10 + 6, 1);
     cov |= y2_spread<NX, NY>(accept);                                    // paint coverage (:4029-4037): bit = lane = cell
@@ -446,8 +477,23 @@ extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMem
 // values of the other lanes of the lane's quad (= its 8x8 tile) as DPP operands
 #define Y2_QUAD_X 0xB1                                                   // quad_perm:[1,0,3,2]: the cell beside this one
 #define Y2_QUAD_Y 0x4E                                                   // quad_perm:[2,3,0,1]: the cell above / below
-template <int CTRL> __device__ __forceinline__ int y2_quad(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ int y2_quad(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, true); }   // every lane is written: no initialising move
 template <int CTRL> __device__ __forceinline__ float y2_quad(float v) { return __int_as_float(y2_quad<CTRL>(__float_as_int(v))); }
+// t[m] += its values in the other three lanes of the quad, for modes FIRST..5: the DPP operand of the add itself.  One block of assembly: the
+// vectoriser otherwise pairs the adds into v_pk_add_f32 (no DPP operand: two moves per value), and a DPP read needs two wait states behind the
+// VALU write of its register, which the compiler does not track inside inline assembly: the block opens with s_nop 1 and a register is
+// read again only after the adds of the other modes (at least two instructions).
+template <int FIRST> __device__ __forceinline__ void y2_quad_sums(float (&t)[6]) {
+#define Y2_QX(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define Y2_QY(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+    if (FIRST == 0)
+        asm volatile("s_nop 1\n\t" Y2_QX(0) Y2_QX(1) Y2_QX(2) Y2_QX(3) Y2_QX(4) Y2_QX(5) Y2_QY(0) Y2_QY(1) Y2_QY(2) Y2_QY(3) Y2_QY(4) Y2_QY(5)
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+    else
+        asm volatile("s_nop 1\n\t" Y2_QX(0) Y2_QX(1) Y2_QX(2) Y2_QY(0) Y2_QY(1) Y2_QY(2) : "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+#undef Y2_QX
+#undef Y2_QY
+}
 // 4 * byte `ch` of w in one instruction (SDWA byte select feeding the shift)
 __device__ __forceinline__ uint32_t y2_byte_x4(uint32_t w, int ch) {
     uint32_t r; const uint32_t two = 2u;
@@ -656,7 +702,8 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
-            y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+            if (deadLanes == 0ULL) y2_grad_pass<4, 4, true>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+            else y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
             if (~(cov | deadLanes) != 0ULL) {
                 y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
                 y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
@@ -856,22 +903,35 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the tile's sums over its quad; mode selection: the reference keeps mode m when err_m <= best, i.e. the running minimum with
-            // the later mode on ties; `near` = the two sums are neither surely ordered nor exactly equal
-            int bestMode = kStart; float bestT = 0.0f;
-            bool amb = false;
-            uint32_t ties = 0;                                               // bit m: mode m tied with the best so far (bits 8+3m..: that mode)
+            // the tile's sums over its quad (DPP operands of the add itself); mode selection: the reference keeps mode m when err_m <= best, i.e.
+            // the running minimum with the later mode on ties.  The common case only asks whether two sums are surely ordered; everything
+            // about sums that are not (`near`: equal, both zero, or closer than the margin) is worked out below, rarely.
+            float tm[6] = { sm[0], sm[1], sm[2], sm[3], sm[4], sm[5] };
+            y2_quad_sums<kStart>(tm);
+            int bestMode = kStart; float bestT = tm[kStart];
+            bool near = false;
 #pragma unroll
-            for (int m = kStart; m < 6; m++) {
-                float t = sm[m];
-                t = __fadd_rn(t, y2_quad<Y2_QUAD_X>(t)); t = __fadd_rn(t, y2_quad<Y2_QUAD_Y>(t));
-                if (m == kStart) { bestT = t; continue; }
+            for (int m = kStart + 1; m < 6; m++) {
+                const float t = tm[m];
                 const float lo = fminf(t, bestT), hi = fmaxf(t, bestT);
-                const bool eq = (t == bestT);
-                amb |= !eq && !(__fmul_rn(lo, 1.00002f) < hi);                // not surely ordered
-                if (eq && t != 0.0f) ties |= (1u << m) | ((uint32_t)bestMode << (8 + 3 * m));   // both exactly zero needs no check
+                near |= !(__fmul_rn(lo, 1.00002f) < hi);                      // not surely ordered (this includes the exact ties)
                 bestMode = (t <= bestT) ? m : bestMode;
                 bestT = lo;
+            }
+            bool amb = false;
+            uint32_t ties = 0;                                               // bit m: mode m tied with the best so far (bits 8+3m..: that mode)
+            if (__ballot(near && tileLive) != 0ULL) {                        // wave-uniform, rare: the walk again, with the reasons
+                int bm = kStart; float bt = tm[kStart];
+#pragma unroll
+                for (int m = kStart + 1; m < 6; m++) {
+                    const float t = tm[m];
+                    const float lo = fminf(t, bt), hi = fmaxf(t, bt);
+                    const bool eq = (t == bt);
+                    amb |= !eq && !(__fmul_rn(lo, 1.00002f) < hi);            // neither surely ordered nor exactly equal
+                    if (eq && t != 0.0f) ties |= (1u << m) | ((uint32_t)bm << (8 + 3 * m));   // both exactly zero needs no check
+                    bm = (t <= bt) ? m : bm;
+                    bt = lo;
+                }
             }
             // exact ties: the later mode wins when the two modes' minDiffs agree on every valid pixel of the tile (identical sums in the
             // reference too); otherwise the tile is ambiguous.  Flat tiles tie all the time (a smooth region next to a contour): instead of
