@@ -470,6 +470,9 @@ extern "C" int yk_debug_wave_times(unsigned long long* out) { return (int)hipMem
 #ifndef YK2_WIN
 #define YK2_WIN 16
 #endif
+#ifndef YK2_PREF
+#define YK2_PREF 8                                                       // rows of a plane requested before the previous plane is finished
+#endif
 #ifndef YK2_RVWIN
 #define YK2_RVWIN 8
 #endif
@@ -861,6 +864,19 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         // the quantiser table's rows start 256 rows before the table (the row base of the definition table is biased by +256)
         const uint8_t* const qrows = P.qtab - (size_t)256 * 16;
+        // ---- nearest LUT entry per pixel and mode: ONE 16-byte row of the quantiser table per pixel and plane, all sixteen of a plane in flight at once
+        uint4 win[16];
+        auto issueRows = [&](const int pl, const int k0, const int k1) {
+            if (valid && !(P.ablate & 4)) {
+                const uint32_t q16 = (tdef[pl] & 0xFFFFu) << 4;
+#pragma unroll
+                for (int k = k0; k < k1; k++) {
+                    const uint32_t v4 = y2_byte_x4(pw[k], pl);                   // 4 * value: a quarter of its row offset
+                    win[k] = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + q16));
+                }
+            }
+        };
+        issueRows(0, 0, YK2_PREF);
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             // ---- nearest LUT entry per pixel and mode: ONE 16-byte row of the quantiser table (yk_qtab_kernel).  Every LUT is
@@ -876,33 +892,29 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             // exactly 0 (all terms 0).  Any other case (rare) flags the tile for exact re-summation in the reference's order.
             const uint32_t qrow16 = (tdef[p] & 0xFFFFu) << 4;               // byte offset of the row of v = 0 behind qrows
             float sm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+            issueRows(p, YK2_PREF, 16);                                       // the rows that were not sent ahead
             if (valid && !(P.ablate & 4)) {
-                // A rolling window of YK2_WIN rows in flight (a row is four registers; all sixteen at once do not fit next to the pixels);
-                // the index words wait in LDS (word = pixel * 64 + lane: conflict-free) until the mode is chosen.
-                uint4 win[YK2_WIN]; float rvw[YK2_RVWIN];
-                auto issueRow = [&](const int k, uint4& row) {
-                    const uint32_t v4 = y2_byte_x4(pw[k], p);                    // 4 * value: LDS offset of its reciprocal, a quarter of its row offset
-                    row = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + qrow16));
-                };
+                // The plane's sixteen rows are in flight already (issued before the previous plane's mode selection, see below); the index
+                // words wait in LDS (word = pixel * 64 + lane: conflict-free) until the mode is chosen.
+                float rvw[YK2_RVWIN];
                 // the reciprocal of the pixel value (a table: v_rcp_f32 is a quarter-rate op, 16 per plane add up); its LDS round trip is short: a small window of its own
                 auto issueRcp = [&](const int k, float& rv) { rv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_rcp) + y2_byte_x4(pw[k], p)); };
-#pragma unroll
-                for (int k = 0; k < YK2_WIN; k++) issueRow(k, win[k]);
 #pragma unroll
                 for (int k = 0; k < YK2_RVWIN; k++) issueRcp(k, rvw[k]);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const uint4 row = win[k % YK2_WIN]; const float rv = rvw[k % YK2_RVWIN];
+                    const uint4 row = win[k]; const float rv = rvw[k % YK2_RVWIN];
                     // sum += minDiff * (1 / v): the f16 halves of the row go straight into the multiply-add (one rounding, like __fmaf_rn on the converted value)
                     if (!MODE3) { y2_fma_lo(sm[0], row.x, rv); y2_fma_hi(sm[1], row.x, rv); y2_fma_lo(sm[2], row.y, rv); }
                     y2_fma_hi(sm[3], row.y, rv); y2_fma_lo(sm[4], row.z, rv); y2_fma_hi(sm[5], row.z, rv);
                     s_iw[k * 64 + lane] = row.w;
-                    if (k + YK2_WIN < 16) issueRow(k + YK2_WIN, win[k % YK2_WIN]);
                     if (k + YK2_RVWIN < 16) issueRcp(k + YK2_RVWIN, rvw[k % YK2_RVWIN]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // the first rows of the next plane leave now: their round trip runs under this plane's mode selection, nibble packing and stores
+            if (p < 2) issueRows(p + 1, 0, YK2_PREF);
             // the tile's sums over its quad (DPP operands of the add itself); mode selection: the reference keeps mode m when err_m <= best, i.e.
             // the running minimum with the later mode on ties.  The common case only asks whether two sums are surely ordered; everything
             // about sums that are not (`near`: equal, both zero, or closer than the margin) is worked out below, rarely.
