@@ -221,10 +221,10 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
         if world > 1:
             blob, _ = pipe.acquire()
             if enc:
-                sizes = enc.export_tile_maps(blob)
-                pipe.submit(int(sizes[14]), sizes)
+                enc.export_tile_maps_framed(blob, torch.cuda.current_stream(dev).cuda_stream)
             else:
-                pipe.submit(0, empty_sizes)                  # a rank without rows still joins the gather, with an empty payload
+                pipe.put(np.zeros(0, np.uint8), empty_sizes)   # a rank without rows still joins the gather, with an empty payload (its header)
+            pipe.submit()
 
     def fence():
         torch.cuda.synchronize()
@@ -256,10 +256,10 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
     if world > 1:
         blob, _ = pipe.acquire()
         if enc:
-            sizes = enc.export_tile_maps(blob)
-            pipe.submit(int(sizes[14]), sizes)
+            enc.export_tile_maps_framed(blob, torch.cuda.current_stream(dev).cuda_stream)
         else:
-            pipe.submit(0, empty_sizes)
+            pipe.put(np.zeros(0, np.uint8), empty_sizes)
+        pipe.submit()
         res = pipe.flush()[-1]
         if rank == 0:
             if W > 16384:
@@ -296,7 +296,7 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
         "dtype": "u8/int32 (+f32 mode-selection sums)", "data": "synthetic (YAIK-synth v1, seed 12345)",
         "config": {"workload": f"ONE {W}x{W} RGBA image per step, full encode ({'3' if args.mode3 else '4'}-bpp range), inputs resident in HBM",
                    "layout": "row stripes", "stripe_rows_rank0": int(h), "blocks_of_64_rows": nblocks,
-                   "parallelism": (f"row stripes x{world}: stripe bbox all-reduce (2 x 2 ints) + ONE gather of the tile maps per image"
+                   "parallelism": (f"row stripes x{world}: one 4-int all-reduce of the stripe bounding boxes + ONE gather of the tile maps per image"
                                    if world > 1 else "single GPU (whole image = one stripe)"),
                    "collective_backend": (dist.get_backend() if world > 1 else None), "collective_world_size": (dist.get_world_size() if world > 1 else 1)},
         "rank0_kernel_ms": {k: round(v, 4) for k, v in kms.items()},
@@ -315,6 +315,126 @@ def bench_stripes(args, rank, world, dist, dev, dev_index, comm_dev, rehearsal) 
     if world > 1:
         dist.destroy_process_group()
     return 0 if (gather_check is None or not gather_check.startswith("MISMATCH")) else 1
+
+
+def abi_gather_check(enc, dist, dev, rank, world, blob, need, allsums, checksum):
+    """The same gather through the C-ABI (yk_comm_* / yk_gather_maps: RCCL bound by the library itself, not through torch), outside the
+    timed region: returns (ok, ranks as RCCL reports them, note).  The communicator is created in a worker thread with a deadline, so a
+    bootstrap that cannot complete on this node is reported instead of hanging the run."""
+    import ctypes as C
+    import threading
+    import torch
+    from yaik_amd._lib import lib
+    L = lib()
+    if not L.yk_comm_available():
+        return True, None, "RCCL could not be loaded by libyaik_hip.so (torch's own path was used and checked)"
+    idbuf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        arr = (C.c_uint8 * 128)()
+        if L.yk_comm_unique_id(arr) != 0:
+            return True, None, "yk_comm_unique_id failed (torch's own path was used and checked)"
+        idbuf = torch.tensor(list(arr), dtype=torch.uint8)
+    idbuf = idbuf.to(dev)
+    dist.broadcast(idbuf, src=0)
+    idbytes = bytes(idbuf.cpu().tolist())
+    comm = C.c_void_p()
+    state = {}
+
+    def init():
+        state["rc"] = L.yk_comm_init_rank(enc._h, idbytes, world, rank, C.byref(comm))
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(120.0)
+    flag = torch.tensor([0 if (not th.is_alive() and state.get("rc") == 0) else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        return True, None, "yk_comm_init_rank did not complete on every rank within 120 s (torch's own path was used and checked)"
+    n, me = C.c_int(), C.c_int()
+    L.yk_comm_ranks(comm, C.byref(n), C.byref(me))
+    needs = [int(t.cpu().tolist()[1]) for t in allsums]
+    offs = [sum(needs[:r]) for r in range(world)]
+    recv = torch.empty(sum(needs), dtype=torch.uint8, device=dev) if rank == 0 else None
+    rb = (C.c_size_t * world)(*needs)
+    ro = (C.c_size_t * world)(*offs)
+    torch.cuda.synchronize()
+    rc = L.yk_gather_maps(enc._h, comm, 0, C.c_void_p(blob.data_ptr()), need, C.c_void_p(recv.data_ptr()) if rank == 0 else None,
+                          rb if rank == 0 else None, ro if rank == 0 else None)
+    enc.synchronize()
+    bad = [] if rc == 0 else [f"yk_gather_maps rc {rc}"]
+    if rank == 0 and rc == 0:
+        for r in range(world):
+            if checksum(recv[offs[r] + 128: offs[r] + needs[r]]) != int(allsums[r].cpu().tolist()[0]):
+                bad.append(f"rank {r}")
+    flag = torch.tensor([len(bad)], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    L.yk_comm_destroy(comm)
+    if int(flag.item()):
+        return False, int(n.value), "payload mismatch through yk_gather_maps: " + ", ".join(bad)
+    return True, int(n.value), f"yk_gather_maps over a {int(n.value)}-rank communicator of its own: every payload arrived byte for byte"
+
+
+def measured_copy_roof(dev, nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """GB/s of a device-to-device copy of `nbytes` on this GPU (read + write counted), outside any timed region (the
+    measured roof next to the 8 TB/s specification)."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(reps):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
+def visible_gpus() -> int:
+    """Number of HIP devices, without initialising one (torch.cuda.device_count() only counts on this image)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n: int, argv=None, count=visible_gpus) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N rank processes of this script as fresh children
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and exit with the
+    launcher's code.  Nothing in this process has touched the GPU yet (a parent that had could not safely start GPU children).
+    Fewer than N devices: an error, never an N = 1 line in disguise.  YK_BENCH_BACKEND=gloo (rehearsal: all ranks on GPU 0,
+    gather through host memory) is exempt from the device count, limited to 6 ranks per card."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    rehearsal = os.environ.get("YK_BENCH_BACKEND", "nccl") != "nccl"
+    have = count()
+    if rehearsal:
+        if have < 1 or n > 6:
+            print(f"bench.py: rehearsal (YK_BENCH_BACKEND=gloo) needs a GPU and at most 6 ranks on it (have {have} GPU, asked for {n} ranks)", file=sys.stderr)
+            return 2
+    elif have < n:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, this node shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)                       # launcher / rank chatter stays out of the one-line contract
+    if lines:
+        print(lines[-1])
+    if proc.returncode == 0 and not lines:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def main() -> int:
@@ -343,10 +463,15 @@ def main() -> int:
     ap.add_argument("--cpu-size", type=int, default=0, help="side of the centred crop timed on the CPU (default: whole frame)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)                       # before anything touches the GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE=1: refusing to report a {args.gpus}-GPU line from one rank", file=sys.stderr)
+            return 2
         args.gpus = world
 
     import numpy as np
@@ -405,10 +530,6 @@ def main() -> int:
     # N > 1: every rank encodes its own frame; the ONE collective of the path, the gather of the packed tile maps onto rank 0,
     # is double-buffered so that the RCCL transfer of frame i rides under the encode kernels of frame i+1.
     pipe = ykd.TileMapGatherPipeline(dist, comm_dev, enc.export_capacity(), dst=0, staging_device=dev) if world > 1 else None
-
-    use_async = world > 1 and not rehearsal    # device-side hand-over to the communicator's stream (needs the payload in HBM)
-    deferred = []                              # rehearsal only: (nbytes, sizes) of exports whose gather is launched under the next step
-
     # frames of at least four rounds of strip-waves: the fused kernels of the frames in flight take turns (two of them sharing the chip
     # only slow each other down); smaller frames need each other's waves to fill the chip and stay unordered
     ordered = K > 1 and not BF and not args.graph and not args.free_overlap and W * W >= 8192 * 8192
@@ -426,29 +547,18 @@ def main() -> int:
                 e.alpha_finish(None)
                 e.encode(3, args.mode3, False)
         if world > 1:
-            while deferred:
-                pipe.submit(*deferred.pop(0))
-            for j, e in enumerate(encs):
+            for e in encs:
                 blob, _ = pipe.acquire()       # waits for the gather that used this buffer two submits ago
-                if use_async and pipe.pad != 0:
-                    # one packing kernel behind the encode on the handle's stream; the RCCL ops are enqueued behind torch's current
-                    # stream, which is made to wait for that kernel on the device: the host never waits for the frame it just queued
-                    e.export_tile_maps_async(blob, pipe.meta_tensor(), torch.cuda.current_stream(dev).cuda_stream)
-                    pipe.submit()
-                else:
-                    sizes = e.export_tile_maps(blob)   # packing kernel + stream sync: the blob is complete on return
-                    if use_async or j + 1 < len(encs):
-                        pipe.submit(int(sizes[14]), sizes)
-                    else:
-                        deferred.append((int(sizes[14]), sizes))
+                # one packing kernel behind the encode on the handle's stream writes header + sections; the transfers are enqueued behind
+                # torch's current stream, which is made to wait for that kernel on the device: the host never waits for the frame it queued
+                e.export_tile_maps_framed(blob, torch.cuda.current_stream(dev).cuda_stream)
+                pipe.submit()                  # the ONE collective of the step (per frame): a grouped launch of point-to-point transfers
 
     def fence():
         torch.cuda.synchronize()
         for e in encs:
             e.synchronize()
         if world > 1:
-            while deferred:
-                pipe.submit(*deferred.pop(0))
             pipe.flush()                       # every gather has landed on rank 0 before the clock stops
             dist.barrier()
         torch.cuda.synchronize()
@@ -480,32 +590,34 @@ def main() -> int:
         kms[n] /= max(1, args.steps)
 
     # ---- N > 1: check the collective's data path outside the timed region: every rank's payload must arrive on rank 0 byte for
-    # byte (compared through 64-bit checksums), for the host-fenced export and for the device-side hand-over
-    gather_check = None
+    # byte (compared through 64-bit checksums), through the pipeline the timed loop used and through the C-ABI gather (yk_gather_maps)
+    gather_check, rccl_ranks, abi_note = None, None, None
     if world > 1:
+        collectives_per_step = (pipe.collectives - pipe.regathers) / max(1, pipe.step)
+
         def checksum(t):
             v = t.to(torch.int64)
             idx = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64)
             return int(((v * (idx % 65521 + 1)).sum() + v.numel()).item())
         bad = []
-        for mode in (("host", "device") if use_async else ("host",)):
-            blob, _ = pipe.acquire()
-            if mode == "host":
-                sizes = enc.export_tile_maps(blob)
-                pipe.submit(int(sizes[14]), sizes)
-            else:
-                enc.export_tile_maps_async(blob, pipe.meta_tensor(), torch.cuda.current_stream(dev).cuda_stream)
-                pipe.submit()
-            res = pipe.flush()[-1]
-            ref_sizes = enc.export_tile_maps(blob)                               # blob is free again after the flush
-            mine = torch.tensor([checksum(blob[: int(ref_sizes[14])]), int(ref_sizes[14])], dtype=torch.int64, device=comm_dev)
-            allsums = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allsums, mine)
-            if rank == 0:
-                for r, (sz, payload) in enumerate(res):
-                    want = allsums[r].cpu().tolist()
-                    if int(sz[14]) != want[1] or checksum(payload.to(dev)) != want[0]:
-                        bad.append(f"{mode}: rank {r}")
+        blob, _ = pipe.acquire()
+        enc.export_tile_maps_framed(blob, torch.cuda.current_stream(dev).cuda_stream)
+        pipe.submit()
+        res = pipe.flush()[-1]
+        enc.synchronize()
+        need = ykd.HEADER_BYTES + int(blob[:8].cpu().view(torch.int64)[0].item())
+        mine = torch.tensor([checksum(blob[ykd.HEADER_BYTES:need]), need], dtype=torch.int64, device=comm_dev)
+        allsums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsums, mine)
+        if rank == 0:
+            for r, (sz, payload) in enumerate(res):
+                want = allsums[r].cpu().tolist()
+                if ykd.HEADER_BYTES + int(sz[14]) != want[1] or checksum(payload.to(dev)) != want[0]:
+                    bad.append(f"pipeline: rank {r}")
+        if not rehearsal:
+            ok, rccl_ranks, abi_note = abi_gather_check(enc, dist, dev, rank, world, blob, need, allsums, checksum)
+            if not ok:
+                bad.append("C-ABI gather: " + abi_note)
         gather_check = "ok" if not bad else "MISMATCH " + ", ".join(bad)
 
     if rank != 0:
@@ -536,8 +648,10 @@ def main() -> int:
                 valu = tj.get("valu_wave_instructions")
             else:
                 traffic_src = "stale: profiles/traffic.json was measured on another version of yk_encode2.hip (re-run tools/profile_round.sh)"
+    roof = measured_copy_roof(dev)                              # after the timed region
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "peak_measured": round(roof, 1), "frac_of_measured": round(achieved / roof, 4),
+                "peak_measured_how": "1 GiB device-to-device copy on this GPU, best of 5, read + write bytes", "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
                 "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (2 kernels)": round(kms["pack"], 4)}}
     if valu and kms["encode"] > 0:
@@ -568,6 +682,12 @@ def main() -> int:
                    "parallelism": f"frame-sharded x{world}, one RCCL gather of tile maps" if world > 1 else "single GPU"},
         "roofline": roofline,
     }
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks if rccl_ranks is not None else None
+        result["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_frame": round(collectives_per_step, 3),
+                                "repeated_transfers": pipe.regathers, "impl": "torch.distributed.batch_isend_irecv: one grouped launch of ncclSend / ncclRecv per frame, "
+                                "counts agreed from the 128-byte header of the same buffer's previous payload (no size exchange)",
+                                "c_abi": abi_note}
     if gather_check is not None:
         result["gather_check"] = gather_check
         if gather_check != "ok":

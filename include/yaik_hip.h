@@ -34,7 +34,8 @@ enum yk_status {
     YK_ERR_BAD_ARG = -2,
     YK_ERR_HIP = -3,            /* a HIP call failed; see yk_last_error */
     YK_ERR_STATE = -4,          /* call order violated (e.g. encode before binding planes) */
-    YK_ERR_RANGE = -5           /* output buffer too small */
+    YK_ERR_RANGE = -5,          /* output buffer too small */
+    YK_ERR_COMM = -6            /* RCCL missing or a RCCL call failed; see yk_last_error */
 };
 
 /* number of gradient passes and their (tileShiftX, tileShiftY) in the shipped order
@@ -221,6 +222,41 @@ int    yk_export_tile_maps(yk_ctx* c, void* devDst, size_t cap, uint64_t sizes[1
  * receives {total payload bytes, sizes[0..14]}; work queued afterwards on `consumerStream` (same runtime instance, 0 = null
  * stream; e.g. the stream a RCCL collective is enqueued behind) sees the finished buffer and table (yk_stream_handoff). */
 int    yk_export_tile_maps_async(yk_ctx* c, void* devDst, size_t cap, void* devMeta16, void* consumerStream);
+/* The framed form the gather moves: devDst[0..127] = 16 x u64 header {payload bytes, sizes[0..14]}, the sections behind it (cap >= 128 +
+ * yk_export_capacity).  A receiver needs nothing but the buffer: the size table travels inside it, and the length to transfer for a LATER
+ * payload of the same rank is agreed from this header on both sides -- no second collective.  No host synchronisation; work queued
+ * afterwards on consumerStream (0 = null stream, (void*)-1 = no hand-over: the gather then goes to the handle's own stream) sees the buffer. */
+#define YK_EXPORT_HEADER_BYTES 128
+int    yk_export_tile_maps_framed(yk_ctx* c, void* devDst, size_t cap, void* consumerStream);
+
+/* ---- the multi-GPU gather of the tile maps (SURVEY 8(b) `yk_gather_maps`, 8(e); new: the reference is one process,
+ * include/YAIK.h:42-47) ------------------------------------------------------------------------------------------------
+ * Row stripes / frames are independent given their pixels; the only exchange is the concatenation of the per-rank tile maps on a root.
+ * RCCL over xGMI, bound at run time (librccl.so.1); communicators are opaque pointers owned by the caller.  A gather is ONE grouped launch
+ * of point-to-point transfers (every sender uses its own direct link into the root) on the handles' streams, behind the kernels that
+ * produced the payloads: nothing is synchronised, the host never waits for the frame it just queued.
+ *   one process per GPU:  id on rank 0 (yk_comm_unique_id), passed to the others by the launcher's own means, yk_comm_init_rank on
+ *                         every rank, then yk_gather_maps per image / frame;
+ *   one process, n GPUs:  yk_comm_init_all over n handles (one per device), then yk_gather_maps_all. */
+/* HBM scratch for hosts that do not link the HIP runtime themselves (the C++ mirror is plain g++): buffers on the handle's device;
+ * yk_device_download copies to the host on the handle's stream and synchronises it. */
+int  yk_device_alloc(yk_ctx* c, size_t bytes, void** dev);
+void yk_device_free(yk_ctx* c, void* dev);
+int  yk_device_download(yk_ctx* c, void* host, const void* dev, size_t bytes);
+int  yk_comm_available(void);                                           /* 1 when RCCL could be loaded */
+int  yk_comm_unique_id(void* id128);                                    /* 128 bytes (ncclUniqueId) */
+int  yk_comm_init_rank(yk_ctx* c, const void* id128, int nRanks, int rank, void** comm);
+int  yk_comm_init_all(yk_ctx* const* ctxs, int n, void** comms);        /* comms[n] out */
+int  yk_comm_ranks(void* comm, int* nRanks, int* rank);                 /* what RCCL reports for the communicator */
+void yk_comm_destroy(void* comm);
+/* Rank side (one process per GPU): every rank but `root` sends sendBytes from devSend; the root receives recvBytes[r] bytes of rank r at
+ * devRecv + recvOffsets[r] (its own payload is copied there on the device; recvBytes / recvOffsets / devRecv may be NULL elsewhere).
+ * Sender and root must name the same count for a rank: derive it on both sides from that rank's previous header. */
+int  yk_gather_maps(yk_ctx* c, void* comm, int root, const void* devSend, size_t sendBytes,
+                    void* devRecv, const size_t* recvBytes, const size_t* recvOffsets);
+/* One process driving n devices: rank r's sendBytes[r] bytes land at devRecv + recvOffsets[r] on the root's device. */
+int  yk_gather_maps_all(yk_ctx* const* ctxs, void* const* comms, int n, int root, void* const* devSend, const size_t* sendBytes,
+                        void* devRecv, const size_t* recvOffsets);
 
 /* ---- decode side: the loops behind YAIK_DecodeImage's chunk switch (decoder/YAIK_API.cpp:731-1303) ----
  * Buffers mirror YAIK_Instance (include/YAIK_private.h:26-54): planeR/G/B u8 in 8x8 tiles, mapRGB lattice,

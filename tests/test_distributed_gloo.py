@@ -42,12 +42,11 @@ def _worker(rank, world, port, q):
     try:
         m, bitmaps, keep, defs, nibs, nn = _encode_on_oracle(_frame(rank))
         payload, sizes = ykd.pack_blob(bitmaps, keep, defs, nibs, nn)
-        blob = torch.from_numpy(payload.copy())
         # the row-stripe layout's only other exchange: image-wide kept-tile bbox
         stripe_box = np.array([16 * (rank + 1), 32 * (rank + 1), 200 - 8 * rank, 240 - 16 * rank], dtype=np.int32)
         gb = ykd.allreduce_bbox(stripe_box, dist, torch.device("cpu"))
         assert gb.tolist() == [16, 32, 200, 240]
-        got = ykd.gather_tile_maps(blob, payload.size, sizes, dist, dst=0)
+        got = ykd.gather_tile_maps(payload, sizes, dist, torch.device("cpu"), dst=0)
         if rank == 0:
             assert got is not None and len(got) == world
             for r, (sz, pl) in enumerate(got):
@@ -91,8 +90,9 @@ def _pipe_worker(rank, world, port, q):
     try:
         cap = 1 << 16
         pipe = ykd.TileMapGatherPipeline(dist, torch.device("cpu"), cap, dst=0)
-        # payload sizes per step: steady, then a jump beyond the 12.5 % headroom on rank 1 (forces the safe re-gather), then steady
-        sizes_per_step = [5000, 5100, 5050, 9000 if rank == 1 else 5000, 9000, 8000]
+        # payload sizes per step: steady, then a jump beyond the 12.5 % headroom on rank 1 (its transfer is repeated with the true length when
+        # the step is retired), a bigger one on both ranks, then shrinking again
+        sizes_per_step = [5000, 5100, 5050, 9000 if rank == 1 else 5000, 12000, 8000, 3000]
         results = []
 
         def payload(step, r, n):
@@ -105,26 +105,26 @@ def _pipe_worker(rank, world, port, q):
             buf, done = pipe.acquire()
             if step >= 2:
                 take(done)
-            buf[:n] = torch.from_numpy(payload(step, rank, n))
             sz = np.zeros(15, np.int64); sz[14] = n; sz[0] = step
-            if step == 0 or step % 2:
-                pipe.submit(n, sz)                              # size table from the host
-            else:
-                m = pipe.meta_tensor()                          # size table already "on the device" (asynchronous exporter)
-                m[0] = n; m[1:16] = torch.from_numpy(sz)
-                pipe.submit()
+            pipe.put(payload(step, rank, n), sz)               # header + sections, as yk_export_tile_maps_framed leaves them on the device
+            pipe.submit()
         for done in pipe.flush():
             take(done)
         assert len(results) == len(sizes_per_step), len(results)
+        # one grouped launch per step, plus one per repeated transfer: rank 1's payloads of step 3 (9000 against the 8192 agreed from step 1)
+        # and of step 4 (12000 against the 8192 agreed from step 2; rank 0 is the root, its own payload never travels); step 5 fits the
+        # count learnt from step 3
         if rank == 0:
-            assert pipe.regathers == 2, pipe.regathers      # steps 3 and 4: the new length is only known when step 3 retires
             for step, res in enumerate(results):
                 for r, (sz, pl) in enumerate(res):
                     n = 9000 if (step == 3 and r == 1) else sizes_per_step[step]
                     assert int(sz[14]) == n and int(sz[0]) == step, (step, r, sz)
                     assert np.array_equal(pl.numpy(), payload(step, r, n)), (step, r)
+            assert pipe.regathers == 2, pipe.regathers
+            assert pipe.collectives == len(sizes_per_step) + 2, pipe.collectives
         else:
-            assert pipe.regathers == 2 and all(x is None for x in results)
+            assert all(x is None for x in results)
+            assert pipe.regathers == 2 and pipe.collectives == len(sizes_per_step) + 2, (pipe.regathers, pipe.collectives)
         dist.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

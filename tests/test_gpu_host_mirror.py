@@ -142,3 +142,30 @@ def test_cpp_lut3d_surface(oracle_built, w, h, seed):
     codes = np.frombuffer(got["yaik_lut_codes"], np.int32).tolist()
     assert codes[0] != 0 and codes[1] == 0, codes                # refused without the LUT, decoded with it
     assert got["yaik_planes_tiled"] == od.planes().tobytes()
+
+
+@pytest.mark.parametrize("case,n", [("synth512x4", 2), ("synth512x4", 8), ("synth1024x4", 3), ("mixed256x3", 4), ("synth256x4", 6)])
+def test_cpp_row_stripes_equal_the_whole_image(case, n):
+    """EncoderContext::ConvertHotPathStripes (n row stripes, one handle each; distinct devices are gathered by ONE grouped RCCL transfer,
+    stripes that share the only device of this box are read back one by one) against the same C++ surface on the whole image."""
+    planes = {"synth512x4": lambda: synth_planes(512, n_planes=4), "synth1024x4": lambda: synth_planes(1024, n_planes=4),
+              "mixed256x3": lambda: edge_image(256, 256, "mixed", 3), "synth256x4": lambda: synth_planes(256, n_planes=4)}[case]()
+    if not os.path.exists(DRIVER):
+        subprocess.run(["make", "-C", os.path.dirname(DRIVER)], check=True)
+    c, h, w = planes.shape
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.blobs")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<3i", w, h, c)); f.write(np.ascontiguousarray(planes, np.int32).tobytes())
+        subprocess.run([DRIVER, fin, fout, "stripes", str(n)], check=True)
+        got = parse_blobs(fout)
+    bad = [f"bitmap{i}" for i in range(7) if got[f"st_bitmap_{i}"] != got[f"wh_bitmap_{i}"]]
+    for p in range(3):
+        bad += [f"{k}{p}" for k in ("defs", "nibbles", "nn") if got[f"st_{k}_{p}"] != got[f"wh_{k}_{p}"]]
+    info = np.frombuffer(got["st_info"], np.int32)
+    if info[:4].tolist() != np.frombuffer(got["wh_bounds"], np.int32).tolist():
+        bad.append(f"bounds {info[:4].tolist()}")
+    assert not bad, bad
+    assert info[4] == min(n, (h + 63) // 64)                 # stripes that own rows
+    import torch
+    assert info[5] == (info[4] if torch.cuda.device_count() >= info[4] > 1 else 0)   # ranks of the RCCL gather, 0 when the stripes shared a device

@@ -86,6 +86,18 @@ SIGNATURES = {
     "yk_export_capacity": (sz, [vp]),
     "yk_export_tile_maps": (C.c_int, [vp, vp, sz, vp]),
     "yk_export_tile_maps_async": (C.c_int, [vp, vp, sz, vp, vp]),
+    "yk_export_tile_maps_framed": (C.c_int, [vp, vp, sz, vp]),
+    "yk_device_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "yk_device_free": (None, [vp, vp]),
+    "yk_device_download": (C.c_int, [vp, vp, vp, sz]),
+    "yk_comm_available": (C.c_int, []),
+    "yk_comm_unique_id": (C.c_int, [vp]),
+    "yk_comm_init_rank": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "yk_comm_init_all": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+    "yk_comm_ranks": (C.c_int, [vp, ip, ip]),
+    "yk_comm_destroy": (None, [vp]),
+    "yk_gather_maps": (C.c_int, [vp, vp, C.c_int, vp, sz, vp, szp, szp]),
+    "yk_gather_maps_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp), szp, vp, szp]),
     "yk_stream_wait_for": (C.c_int, [vp, vp]),
     "yk_stream_handoff": (C.c_int, [vp, vp]),
     "yk_decode_begin": (C.c_int, [vp, C.c_int, C.c_int]),

@@ -649,6 +649,15 @@ int yk_export_tile_maps_async(yk_ctx* c, void* devDst, size_t cap, void* devMeta
     return yk_stream_handoff(c, consumerStream);
 }
 
+int yk_export_tile_maps_framed(yk_ctx* c, void* devDst, size_t cap, void* consumerStream) {
+    if (!c || !devDst) return YK_ERR_BAD_ARG;
+    if (cap < YK_EXPORT_HEADER_BYTES) return yk_fail(c, YK_ERR_RANGE, "export buffer smaller than its header");
+    int rc = yk_export_launch(c, static_cast<uint8_t*>(devDst) + YK_EXPORT_HEADER_BYTES, cap - YK_EXPORT_HEADER_BYTES, reinterpret_cast<unsigned long long*>(devDst));
+    if (rc) return rc;
+    if (consumerStream == reinterpret_cast<void*>(-1)) return YK_OK;
+    return yk_stream_handoff(c, consumerStream);
+}
+
 int yk_stream_handoff(yk_ctx* c, void* consumerStream) {
     if (!c) return YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));

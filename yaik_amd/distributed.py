@@ -42,53 +42,42 @@ def combine_bboxes(boxes: np.ndarray) -> np.ndarray:
 
 
 def allreduce_bbox(bbox: np.ndarray, dist, device) -> np.ndarray:
-    """Image-wide bbox from per-rank stripe boxes: two tiny all-reduces (MIN on x0,y0 / MAX on x1,y1)."""
+    """Image-wide bbox from per-rank stripe boxes: ONE tiny all-reduce (MAX over {-x0, -y0, x1, y1}).  Only the multi-process layout
+    needs it; one process driving all GPUs combines the boxes on the host (EncoderContext::ConvertHotPathStripes)."""
     import torch
-    lo = torch.tensor([int(bbox[0]), int(bbox[1])], dtype=torch.int32, device=device)
-    hi = torch.tensor([int(bbox[2]), int(bbox[3])], dtype=torch.int32, device=device)
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    lo = lo.cpu().numpy(); hi = hi.cpu().numpy()
-    return np.array([lo[0], lo[1], hi[0], hi[1]], dtype=np.int32)
+    v = torch.tensor([-int(bbox[0]), -int(bbox[1]), int(bbox[2]), int(bbox[3])], dtype=torch.int32, device=device)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    v = v.cpu().numpy()
+    return np.array([-v[0], -v[1], v[2], v[3]], dtype=np.int32)
 
 
-def gather_tile_maps(blob, nbytes: int, sizes: np.ndarray, dist, dst: int = 0):
-    """ONE gather of the per-rank tile-map blobs (uint8 tensors, device or CPU) onto rank `dst`.
+HEADER_BYTES = 128          # 16 x u64: payload bytes (the sections behind the header), then the 15 section sizes (yk_export_tile_maps_framed)
 
-    Ranks first agree on the padded length (all_gather of 16 int64: payload bytes + the 15 section sizes), then
-    gather equal-size slices.  Returns on dst: list of (sizes[15], uint8 tensor view of that rank's payload); else None.
-    """
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    meta = torch.zeros(16, dtype=torch.int64, device=blob.device)
-    meta[0] = int(nbytes)
-    meta[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=blob.device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    metas = torch.stack(metas).cpu().numpy()
-    pad = int(metas[:, 0].max())
-    pad = (pad + 255) & ~255
-    send = blob[:pad] if blob.numel() >= pad else torch.cat([blob, blob.new_zeros(pad - blob.numel())])
-    if rank == dst:
-        recv = [torch.empty(pad, dtype=torch.uint8, device=blob.device) for _ in range(world)]
-        dist.gather(send, recv, dst=dst)
-        return [(metas[r, 1:16].copy(), recv[r][: int(metas[r, 0])]) for r in range(world)]
-    dist.gather(send, None, dst=dst)
-    return None
+
+def frame_payload(payload: np.ndarray, sizes: np.ndarray) -> np.ndarray:
+    """Host-side twin of yk_export_tile_maps_framed: header + sections."""
+    hdr = np.zeros(16, dtype=np.uint64)
+    hdr[0] = int(sizes[14])
+    hdr[1:16] = np.asarray(sizes, dtype=np.uint64)
+    return np.concatenate([hdr.view(np.uint8), np.asarray(payload, dtype=np.uint8)])
 
 
 class TileMapGatherPipeline:
-    """Double-buffered, asynchronous form of gather_tile_maps for streams of frames / stripes.
+    """The ONE collective of the path: the gather of the per-rank tile maps onto rank `dst`, double-buffered for streams of frames / stripes.
 
-    The gather of step i (RCCL kernels on the communicator's stream, xGMI links) overlaps the encode kernels of step i+1.
+    A payload is framed (a 128-byte header with its size table in front of the sections), so the root needs nothing but the bytes.  Payload
+    sizes differ per rank and per frame, and both ends of a transfer must name the same count: the count for rank r at step k is derived,
+    on rank r and on the root alike, from the header of rank r's payload of step k - 2 (+12.5 % headroom) -- the payload that used the same
+    buffer, whose header both have read by then.  A step is therefore exactly one grouped launch of point-to-point transfers
+    (torch.distributed.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL; every sender uses its own xGMI link
+    into the root), with no size exchange next to it.  A payload that outgrows its agreed count arrives truncated; both ends see that in its
+    header when the step is retired and repeat that one transfer with the true length.  One all_gather at set-up agrees the first counts.
+
     Per step:  buf, done = pipe.acquire()   # waits for the gather that last used this buffer (two steps ago), returns its result
-               ... export the tile maps into buf ...
-               pipe.submit(nbytes, sizes)   # launches all_gather(sizes) + gather(payload) and returns immediately
-    and `pipe.flush()` at the end.  All ranks use one padded length per gather, derived from the sizes every rank reported in
-    an EARLIER step (+12.5 % headroom), so no rank waits for a size exchange before sending.  If some rank's payload outgrows
-    that length the step is re-gathered with the safe synchronous protocol when it is retired (every rank sees the same size
-    table, so all ranks take that branch together).  Results (on dst: list of (sizes[15], payload view) per rank; elsewhere
-    None) stay valid until the buffer they came from is acquired again.
+               ... yk_export_tile_maps_framed into buf (or pipe.put(payload, sizes) for host data) ...
+               pipe.submit()                # launches the transfers and returns immediately
+    and `pipe.flush()` at the end.  The gather of step i (RCCL kernels on the communicator's stream) overlaps the encode kernels of step i+1.
+    Results (on dst: list of (sizes[15], payload view) per rank; elsewhere None) stay valid until the buffer they came from is acquired again.
     """
 
     def __init__(self, dist, device, capacity: int, dst: int = 0, headroom: float = 1.125, staging_device=None):
@@ -96,86 +85,106 @@ class TileMapGatherPipeline:
         self.dist, self.dst, self.headroom = dist, dst, headroom
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.comm_device = device
+        self.cap = int(capacity) + HEADER_BYTES
         # staging_device: where the encoder writes (HBM); differs from the communicator's device only in the gloo rehearsal
-        self.blobs = [torch.empty(capacity, dtype=torch.uint8, device=staging_device or device) for _ in range(2)]
+        self.blobs = [torch.zeros(self.cap, dtype=torch.uint8, device=staging_device or device) for _ in range(2)]
         self.send = [None, None]
-        self.meta = [torch.zeros(16, dtype=torch.int64, device=device) for _ in range(2)]
-        self.metas = [[torch.zeros(16, dtype=torch.int64, device=device) for _ in range(self.world)] for _ in range(2)]
-        self.recv = [None, None]
-        self.pad_used = [0, 0]
+        self.recv = [[None] * self.world, [None] * self.world]
+        self.count_used = [[0] * self.world, [0] * self.world]
         self.work = [None, None]
-        self.pad = 0
+        self.agreed = None                                  # [world]: bytes rank r sends in its next transfer (known for all r on dst, for itself elsewhere)
         self.step = 0
         self.regathers = 0
+        self.collectives = 0                                # grouped launches issued (set-up agreement excluded): one per step + one per repeated transfer
 
     def _roundup(self, n: int) -> int:
-        return (int(n * self.headroom) + 4095) & ~4095
+        return min(self.cap, (int(n * self.headroom) + 4095) & ~4095)
 
     def acquire(self):
         slot = self.step & 1
         return self.blobs[slot], self._retire(slot)
 
-    def meta_tensor(self):
-        """int64[16] device tensor of the current buffer: {payload bytes, sizes[0..14]} — the target of an asynchronous export."""
-        return self.meta[self.step & 1]
+    def put(self, payload: np.ndarray, sizes: np.ndarray) -> None:
+        """Host data into the acquired buffer (tests, CPU ranks): header + sections."""
+        import torch
+        framed = frame_payload(payload, sizes)
+        buf = self.blobs[self.step & 1]
+        buf[: framed.size] = torch.from_numpy(framed).to(buf.device)
 
-    def submit(self, nbytes: int | None = None, sizes=None) -> None:
-        """Launch the gather of the acquired buffer.  With (nbytes, sizes) the size table comes from the host; without, it was
-        already written on the device (meta_tensor(), ordered before the communicator's stream by the exporter) — that form
-        needs an agreed length, i.e. at least one earlier submit with host sizes."""
+    def _need(self, blob) -> int:
+        import torch
+        return HEADER_BYTES + int(blob[:8].cpu().view(torch.int64)[0].item())
+
+    def submit(self) -> None:
+        """Launch the gather of the acquired buffer (its header must be in place, written by the exporter on the device or by put())."""
         import torch
         slot = self.step & 1
         assert self.work[slot] is None, "acquire() the buffer before exporting into it"
         dist = self.dist
-        m = self.meta[slot]
-        if nbytes is not None:
-            m[0] = int(nbytes)
-            m[1:16] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=m.device)
-        else:
-            assert self.pad != 0, "the first submit of a pipeline needs the sizes on the host"
-        if self.pad == 0:                                   # first step: agree on a length once, synchronously
-            dist.all_gather(self.metas[slot], m)
-            self.pad = self._roundup(int(torch.stack(self.metas[slot])[:, 0].max().item()))
-            w_meta = None
-        else:
-            w_meta = dist.all_gather(self.metas[slot], m, async_op=True)
-        pad = min(self.pad, self.blobs[slot].numel())
-        src = self.blobs[slot][:pad]
-        if src.device != self.comm_device:
-            src = src.to(self.comm_device)
-        self.send[slot] = src                               # keep alive until retired
+        if self.agreed is None:                             # set-up, once: every rank tells the length of its first payload
+            mine = torch.tensor([self._need(self.blobs[slot])], dtype=torch.int64, device=self.comm_device)
+            alln = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(alln, mine)
+            self.agreed = [self._roundup(int(t.item())) for t in alln]
+        ops, counts = [], list(self.agreed)
         if self.rank == self.dst:
-            if self.recv[slot] is None or self.recv[slot][0].numel() != pad:
-                self.recv[slot] = [torch.empty(pad, dtype=torch.uint8, device=self.comm_device) for _ in range(self.world)]
-            w = dist.gather(src, self.recv[slot], dst=self.dst, async_op=True)
+            for r in range(self.world):
+                if r == self.dst:
+                    continue
+                if self.recv[slot][r] is None or self.recv[slot][r].numel() < counts[r]:
+                    self.recv[slot][r] = torch.empty(max(counts[r], HEADER_BYTES), dtype=torch.uint8, device=self.comm_device)
+                ops.append(dist.P2POp(dist.irecv, self.recv[slot][r][: counts[r]], r))
         else:
-            w = dist.gather(src, None, dst=self.dst, async_op=True)
-        self.work[slot] = (w_meta, w)
-        self.pad_used[slot] = pad
+            src = self.blobs[slot][: counts[self.rank]]
+            if src.device != self.comm_device:
+                src = src.to(self.comm_device)
+            self.send[slot] = src                           # keep alive until retired
+            ops.append(dist.P2POp(dist.isend, src, self.dst))
+        self.work[slot] = dist.batch_isend_irecv(ops) if ops else []
+        self.collectives += 1
+        self.count_used[slot] = counts
         self.step += 1
 
     def _retire(self, slot: int):
         import torch
         if self.work[slot] is None:
             return None
-        w_meta, w = self.work[slot]
-        if w_meta is not None:
-            w_meta.wait()
-        w.wait()
+        for w in self.work[slot]:
+            w.wait()
         self.work[slot] = None
-        metas = torch.stack(self.metas[slot]).cpu().numpy()
-        need = int(metas[:, 0].max())
-        pad = self.pad_used[slot]
-        self.pad = max(self.pad, self._roundup(need))
-        if need > pad:                                      # a payload was truncated: repeat this step with the safe protocol
-            self.regathers += 1
-            blob = self.blobs[slot]
-            if blob.device != self.comm_device:
-                blob = blob.to(self.comm_device)
-            return gather_tile_maps(blob, int(metas[self.rank, 0]), metas[self.rank, 1:16], self.dist, dst=self.dst)
+        dist, used = self.dist, self.count_used[slot]
+        blob = self.blobs[slot]
         if self.rank != self.dst:
+            need = self._need(blob)
+            if need > used[self.rank]:                      # truncated: the root reads the same header and posts the matching receive
+                self.regathers += 1
+                src = blob[:need] if blob.device == self.comm_device else blob[:need].to(self.comm_device)
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, self.dst)]):
+                    w.wait()
+                self.collectives += 1
+            self.agreed[self.rank] = self._roundup(need)
             return None
-        return [(metas[r, 1:16].copy(), self.recv[slot][r][: int(metas[r, 0])]) for r in range(self.world)]
+        out, again = [None] * self.world, []
+        for r in range(self.world):
+            buf = blob if r == self.dst else self.recv[slot][r]
+            hdr = buf[:HEADER_BYTES].cpu().view(torch.int64).numpy()
+            need = HEADER_BYTES + int(hdr[0])
+            if r != self.dst and need > used[r]:
+                if self.recv[slot][r].numel() < need:
+                    self.recv[slot][r] = torch.empty(need, dtype=torch.uint8, device=self.comm_device)
+                again.append(dist.P2POp(dist.irecv, self.recv[slot][r][:need], r))
+            self.agreed[r] = self._roundup(need)
+            out[r] = (hdr[1:16].copy(), r, need)
+        if again:
+            self.regathers += 1
+            for w in dist.batch_isend_irecv(again):
+                w.wait()
+            self.collectives += 1
+        res = []
+        for sizes, r, need in out:
+            buf = blob if r == self.dst else self.recv[slot][r]
+            res.append((sizes, buf[HEADER_BYTES:need]))
+        return res
 
     def flush(self) -> list:
         """Retire everything in flight, oldest first; returns their results in that order."""
@@ -185,6 +194,20 @@ class TileMapGatherPipeline:
             if self.work[slot] is not None:
                 out.append(self._retire(slot))
         return out
+
+
+def gather_tile_maps(payload: np.ndarray, sizes: np.ndarray, dist, device, dst: int = 0):
+    """One-shot form (host payload in yk_export_tile_maps' layout + its 15 sizes): set-up agreement + one grouped transfer.
+    Returns on dst: list of (sizes[15], uint8 tensor of that rank's payload); else None."""
+    cap = (int(sizes[14]) + 4095) & ~4095
+    import torch
+    c = torch.tensor([cap], dtype=torch.int64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX)
+    pipe = TileMapGatherPipeline(dist, device, int(c.item()), dst=dst)
+    pipe.acquire()
+    pipe.put(payload, sizes)
+    pipe.submit()
+    return pipe.flush()[-1]
 
 
 def pack_blob(bitmaps, keep, defs, nibbles, n_nibbles) -> tuple[np.ndarray, np.ndarray]:

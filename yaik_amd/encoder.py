@@ -310,6 +310,13 @@ class HipTileEncoder:
         _chk(self._h, lib().yk_export_tile_maps_async(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(),
                                                       C.c_void_p(dev_meta16.data_ptr()), C.c_void_p(consumer_stream)))
 
+    def export_tile_maps_framed(self, dev_buffer, consumer_stream: int | None = 0) -> None:
+        """The form the gather moves (yk_export_tile_maps_framed): dev_buffer[0:128] = header {payload bytes, sizes[0..14]}, the sections
+        behind it; no host synchronisation.  Work queued afterwards on `consumer_stream` (0 = null stream; None = no hand-over) sees the
+        buffer.  The caller orders EARLIER work on the buffer before the handle's stream (idle buffers, or yk_stream_wait_for)."""
+        cs = C.c_void_p(-1 & 0xFFFFFFFFFFFFFFFF) if consumer_stream is None else C.c_void_p(consumer_stream)
+        _chk(self._h, lib().yk_export_tile_maps_framed(self._h, C.c_void_p(dev_buffer.data_ptr()), dev_buffer.numel(), cs))
+
     def kernel_ms(self) -> dict:
         e, a, p = C.c_float(), C.c_float(), C.c_float()
         _chk(self._h, lib().yk_last_kernel_ms(self._h, C.byref(e), C.byref(a), C.byref(p)))

@@ -1,6 +1,7 @@
 // Host side of the drop-in `EncoderContext` for the tile hot path: thin caller of the C-ABI (include/yaik_hip.h).
 // Mirrors the reference's call contract (encoder/EncoderContext.cpp:1227-1427, 2784-2797, 3710-4363, 4365-4602, 8398-8522);
 // every pixel is processed by the HIP kernels, nothing is computed here.
+#include <cstring>
 #include "EncoderContext.h"
 #include <climits>
 #include <condition_variable>
@@ -311,6 +312,115 @@ bool EncoderContext::ConvertHotPath(FILE* f) {
     }
     ok = ok && yaikchunk::writeEndOfFile(f);
     outFile = saved;
+    return ok;
+}
+
+// ---- row stripes over the GPUs of the node -----------------------------------------------------------------------------------------------
+bool EncoderContext::ConvertHotPathStripes(const int* devices, int nStripes, bool mode3BitOnly, StripeTileMaps* out) {
+    if (!original || !devices || !out || nStripes < 1 || nStripes > 64) return fail("ConvertHotPathStripes: an image, 1..64 stripes and a result");
+    const int w = original->GetWidth(), H = original->GetHeight(), np = original->HasAlpha() ? 4 : 3;
+    struct Stripe { yk_ctx* c = nullptr; int y0 = 0, h = 0, halo = 0; void* send = nullptr; size_t bytes = 0; };
+    std::vector<Stripe> st((size_t)nStripes);
+    std::vector<void*> comms;
+    void* recv = nullptr;
+    bool ok = true;
+    auto bad = [&](const char* what) { ok = false; return fail(what); };
+    // the image's 64-row blocks dealt as evenly as possible (swizzle blocks never straddle stripes: per-pass bitmaps concatenate)
+    const int blocks = (H + 63) / 64, base = blocks / nStripes, rem = blocks % nStripes;
+    for (int i = 0; i < nStripes && ok; i++) {
+        const int start = i * base + (i < rem ? i : rem), count = base + (i < rem ? 1 : 0);
+        st[i].y0 = start * 64 < H ? start * 64 : H;
+        const int y1 = (start + count) * 64 < H ? (start + count) * 64 : H;
+        st[i].h = y1 - st[i].y0; st[i].halo = (y1 < H && st[i].h > 0) ? 1 : 0;
+        if (st[i].h == 0) continue;                                      // more stripes than blocks: nothing to do for this one
+        if (yk_create(devices[i], &st[i].c) != YK_OK) { bad("ConvertHotPathStripes: yk_create"); break; }
+        const int32_t* p[4] = { nullptr, nullptr, nullptr, nullptr };
+        for (int k = 0; k < np; k++) p[k] = original->GetPlane(k)->GetPixels() + (size_t)st[i].y0 * w;
+        if (yk_set_image(st[i].c, w, H, np, st[i].y0, st[i].h, st[i].halo) != YK_OK || yk_upload_planes(st[i].c, p, w) != YK_OK) bad("ConvertHotPathStripes: binding a stripe");
+    }
+    int box[4] = { 9999999, 9999999, -1, -1 };
+    if (ok && np == 4) {                                                 // MipPrefilter per stripe, its kept-tile box combined here (min / max)
+        for (auto& s : st) if (s.c && yk_alpha_reject(s.c) != YK_OK) bad("ConvertHotPathStripes: yk_alpha_reject");
+        for (auto& s : st) {
+            int32_t b[4];
+            if (!ok || !s.c) continue;
+            if (yk_get_stripe_bbox(s.c, b) != YK_OK) { bad("ConvertHotPathStripes: yk_get_stripe_bbox"); break; }
+            box[0] = b[0] < box[0] ? b[0] : box[0]; box[1] = b[1] < box[1] ? b[1] : box[1];
+            box[2] = b[2] > box[2] ? b[2] : box[2]; box[3] = b[3] > box[3] ? b[3] : box[3];
+        }
+        const int32_t gb[4] = { box[0], box[1], box[2], box[3] };
+        for (auto& s : st) if (ok && s.c && yk_alpha_finish(s.c, gb) != YK_OK) bad("ConvertHotPathStripes: yk_alpha_finish");
+    }
+    // every stripe's kernels are queued before anything is waited for: the devices work side by side
+    for (auto& s : st) if (ok && s.c && yk_encode_tiles(s.c, 3, mode3BitOnly ? 1 : 0, 0) != YK_OK) bad("ConvertHotPathStripes: yk_encode_tiles");
+    for (auto& s : st) {
+        if (!ok || !s.c) continue;
+        const size_t cap = yk_export_capacity(s.c) + YK_EXPORT_HEADER_BYTES;
+        if (yk_device_alloc(s.c, cap, &s.send) != YK_OK || yk_export_tile_maps_framed(s.c, s.send, cap, reinterpret_cast<void*>(-1)) != YK_OK) bad("ConvertHotPathStripes: export");
+    }
+    std::vector<std::vector<u8>> payload((size_t)nStripes);
+    if (ok) {
+        for (int i = 0; i < nStripes && ok; i++) {                       // the 128-byte headers tell how much each stripe has to send
+            if (!st[i].c) continue;
+            unsigned long long hdr[16];
+            if (yk_device_download(st[i].c, hdr, st[i].send, sizeof hdr) != YK_OK) { bad("ConvertHotPathStripes: header"); break; }
+            st[i].bytes = YK_EXPORT_HEADER_BYTES + (size_t)hdr[0];
+        }
+        std::vector<int> live; bool distinct = true;
+        for (int i = 0; i < nStripes; i++) if (st[i].c) { for (int j : live) if (devices[j] == devices[i]) distinct = false; live.push_back(i); }
+        out->stripes = (int)live.size(); out->gatherRanks = 0;
+        if (ok && live.size() > 1 && distinct && yk_comm_available()) {  // ONE grouped transfer onto the first stripe's device, one copy to the host
+            const int n = (int)live.size();
+            std::vector<yk_ctx*> cs; std::vector<void*> snd; std::vector<size_t> bytes, offs; size_t total = 0;
+            for (int i : live) { cs.push_back(st[i].c); snd.push_back(st[i].send); bytes.push_back(st[i].bytes); offs.push_back(total); total += (st[i].bytes + 255) & ~(size_t)255; }
+            comms.assign((size_t)n, nullptr);
+            if (yk_comm_init_all(cs.data(), n, comms.data()) != YK_OK) bad(yk_last_error(cs[0]));
+            if (ok && yk_device_alloc(cs[0], total, &recv) != YK_OK) bad("ConvertHotPathStripes: receive buffer");
+            if (ok && yk_gather_maps_all(cs.data(), comms.data(), n, 0, snd.data(), bytes.data(), recv, offs.data()) != YK_OK) bad(yk_last_error(cs[0]));
+            for (int k = 1; k < n && ok; k++) if (yk_synchronize(cs[k]) != YK_OK) bad("ConvertHotPathStripes: yk_synchronize");
+            std::vector<u8> all(total);
+            if (ok && yk_device_download(cs[0], all.data(), recv, total) != YK_OK) bad("ConvertHotPathStripes: download");
+            for (int k = 0; k < n && ok; k++) payload[(size_t)live[k]].assign(all.begin() + (long)offs[k], all.begin() + (long)(offs[k] + bytes[k]));
+            if (ok) { int cnt = 0; yk_comm_ranks(comms[0], &cnt, nullptr); out->gatherRanks = cnt; }
+        } else {
+            for (int i : live) {
+                payload[(size_t)i].resize(st[i].bytes);
+                if (ok && yk_device_download(st[i].c, payload[(size_t)i].data(), st[i].send, st[i].bytes) != YK_OK) bad("ConvertHotPathStripes: download");
+            }
+        }
+    }
+    if (ok) {                                                            // concatenate: bitmaps and definitions byte-wise, nibble streams with a 4-bit shift
+        for (int k = 0; k < 7; k++) out->bitmap[k].clear();
+        for (int p = 0; p < 3; p++) { out->defs[p].clear(); out->nibbles[p].clear(); out->nNibbles[p] = 0; }
+        for (int i = 0; i < nStripes; i++) {
+            if (payload[(size_t)i].empty()) continue;
+            const u8* b = payload[(size_t)i].data();
+            unsigned long long hdr[16]; memcpy(hdr, b, sizeof hdr);
+            size_t off = YK_EXPORT_HEADER_BYTES;
+            auto take = [&](size_t n) { const u8* v = b + off; off += (n + 15) & ~(size_t)15; return v; };
+            for (int k = 0; k < 7; k++) { const size_t n = (size_t)hdr[1 + k]; const u8* v = take(n); out->bitmap[k].insert(out->bitmap[k].end(), v, v + n); }
+            take((size_t)hdr[8]);                                        // keep flags: the stripes' own business
+            for (int p = 0; p < 3; p++) {
+                const size_t nd = (size_t)hdr[9 + 2 * p], nn = (size_t)hdr[10 + 2 * p];
+                const u16* d = reinterpret_cast<const u16*>(take(nd * 2));
+                out->defs[p].insert(out->defs[p].end(), d, d + nd);
+                const u8* nb = take((nn + 1) / 2);
+                std::vector<u8>& dst = out->nibbles[p];
+                if ((out->nNibbles[p] & 1) == 0) dst.insert(dst.end(), nb, nb + (nn + 1) / 2);
+                else for (size_t q = 0; q < nn; q++) {                  // the stream so far ends in a half byte
+                    const u8 v = (u8)((nb[q >> 1] >> ((q & 1) * 4)) & 15);
+                    if (((out->nNibbles[p] + q) & 1) == 0) dst.push_back(v); else dst.back() = (u8)(dst.back() | (v << 4));
+                }
+                out->nNibbles[p] += nn;
+                dst.resize((out->nNibbles[p] + 1) / 2);
+            }
+        }
+        if (np == 4) { out->bounds[0] = box[0]; out->bounds[1] = box[1]; out->bounds[2] = box[2]; out->bounds[3] = box[3]; }
+        else { out->bounds[0] = 0; out->bounds[1] = 0; out->bounds[2] = w; out->bounds[3] = H; }
+    }
+    for (void* cm : comms) if (cm) yk_comm_destroy(cm);
+    if (recv) yk_device_free(st[0].c ? st[0].c : nullptr, recv);
+    for (auto& s : st) { if (s.c) { if (s.send) yk_device_free(s.c, s.send); yk_destroy(s.c); } }
     return ok;
 }
 

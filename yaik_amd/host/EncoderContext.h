@@ -63,6 +63,21 @@ public:
     bool ConvertHotPathBegin(FILE* f, int threads);
     bool ConvertHotPathFinish();
     bool ConvertHotPathParallel(FILE* f, int threads) { return ConvertHotPathBegin(f, threads) && ConvertHotPathFinish(); }
+    // The tile maps of the image, encoded as row stripes on several GPUs of the node by THIS process (the reference is one
+    // process, include/YAIK.h:42-47): stripe i = a band of 64-row blocks + one halo row (the BL / BR corner samples at y + T,
+    // EncoderContext.cpp:3853-3856) on devices[i]; the image-wide kept-tile box of MipPrefilter is combined on the host (no collective);
+    // the per-stripe maps are concatenated on the first device by ONE grouped RCCL transfer (yk_gather_maps_all) and come back in one copy.
+    // Stripes that share a device (a one-GPU box) are simply read back one by one.  The result equals the whole-image encode bit for bit:
+    // 7 swizzled bitmaps, and per plane the tile definitions and the nibble stream of DynamicTileEncode.
+    struct StripeTileMaps {
+        std::vector<u8> bitmap[7];
+        std::vector<u16> defs[3];
+        std::vector<u8> nibbles[3];
+        size_t nNibbles[3] = { 0, 0, 0 };
+        int bounds[4] = { 0, 0, 0, 0 };                 // boundX0, boundY0, boundX1, boundY1 of the whole image
+        int stripes = 0, gatherRanks = 0;               // ranks of the RCCL communicator the gather used (0 = no transfer between devices)
+    };
+    bool ConvertHotPathStripes(const int* devices, int nStripes, bool mode3BitOnly, StripeTileMaps* out);
 
     // raw streams of the last call of each kind (what the reference compresses and writes, before entropy coding)
     const std::vector<u8>&  LastGradientBitmap() const { return gradBitmap; }             // pFillBitMap (:3775)

@@ -5,6 +5,8 @@
 // usage: host_driver <in.bin> <out.blobs> [mode3BitOnly] [out.yaik]
 //        host_driver <in.bin> <out.blobs> lut <bank.bin>   3-D LUT tiles (Load3DPattern, Start/Correlation3DSearch x6/EndCorrelationSearch, :9117-9218)
 //                                                   behind the gradient passes, the '3DTL' chunk decoded back after YAIK_AssignLUT (see run_lut)
+//        host_driver <in.bin> <out.blobs> stripes <n>   the tile maps of the image encoded as n row stripes (ConvertHotPathStripes: stripe i on device
+//                                                   i modulo the devices present; distinct devices are gathered by one RCCL transfer) next to the whole-image passes
 //        host_driver <in.bin> <out.blobs> pp        the six plane-subset 4x4 passes of Convert() (:9261-9415) after the RGB passes, written
 //                                                   as a .yaik stream and decoded back (see run_partial below)
 // With the 4th argument the image is also converted to a .yaik stream (ConvertHotPath) and decoded back through the
@@ -15,6 +17,7 @@
 #include <vector>
 #include <unistd.h>
 #include "EncoderContext.h"
+#include "../../include/yaik_hip.h"
 #include "yaik_decode.h"
 #include "chunks.h"
 #include "palette.h"
@@ -185,6 +188,41 @@ int main(int argc, char** argv) {
         fclose(gOut);
         ctx->SetImageToEncode(nullptr); ctx->Release(); delete ctx;
         return rc;
+    }
+    if (argc > 4 && std::string(argv[3]) == "stripes") {
+        // the image as row stripes over the devices of the node, then the whole-image passes for comparison (tests/test_gpu_host_mirror.py)
+        const int n = atoi(argv[4]);
+        const int have = yk_device_count();
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; i++) devs[(size_t)i] = have > 0 ? i % have : 0;
+        EncoderContext::StripeTileMaps maps;
+        if (!ctx->ConvertHotPathStripes(devs.data(), n, mode3, &maps)) { fprintf(stderr, "ConvertHotPathStripes: %s\n", ctx->LastError()); return 4; }
+        for (int i = 0; i < 7; i++) blob(nm("st_bitmap", i), maps.bitmap[i].data(), maps.bitmap[i].size());
+        for (int p = 0; p < 3; p++) {
+            blob(nm("st_defs", p), maps.defs[p].data(), maps.defs[p].size() * 2);
+            blob(nm("st_nibbles", p), maps.nibbles[p].data(), maps.nibbles[p].size());
+            unsigned long long nn = maps.nNibbles[p]; blob(nm("st_nn", p), &nn, sizeof nn);
+        }
+        int info[6] = { maps.bounds[0], maps.bounds[1], maps.bounds[2], maps.bounds[3], maps.stripes, maps.gatherRanks };
+        blob("st_info", info, sizeof info);
+        if (np == 4) ctx->MipPrefilter(true);
+        static const int passes[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+        for (int i = 0; i < 7; i++) {
+            ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), nullptr, false, passes[i][0], passes[i][1]);
+            blob(nm("wh_bitmap", i), ctx->LastGradientBitmap().data(), ctx->LastGradientBitmap().size());
+        }
+        for (int p = 0; p < 3; p++) {
+            ctx->DynamicTileEncode(false, img->GetPlane(p), nullptr, false, false, false, false);
+            blob(nm("wh_defs", p), ctx->LastTileDefs().data(), ctx->LastTileDefs().size() * 2);
+            blob(nm("wh_nibbles", p), ctx->LastTileIndexStream().data(), ctx->LastTileIndexStream().size());
+            unsigned long long nn = ctx->LastTileIndexCount(); blob(nm("wh_nn", p), &nn, sizeof nn);
+        }
+        int wb[4] = { ctx->boundX0, ctx->boundY0, ctx->boundX1, ctx->boundY1 };
+        blob("wh_bounds", wb, sizeof wb);
+        if (*ctx->LastError()) { fprintf(stderr, "%s\n", ctx->LastError()); return 4; }
+        fclose(gOut);
+        ctx->SetImageToEncode(nullptr); ctx->Release(); delete ctx;
+        return 0;
     }
     if (argc > 3 && std::string(argv[3]) == "pp") {
         const int rc = run_partial(ctx, img, w, h, np);
