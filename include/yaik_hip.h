@@ -50,6 +50,8 @@ const char* yk_last_error(const yk_ctx* c);
  * other stream of the process: fence hand-overs of buffers on the host, or pass the producer's / consumer's stream here.
  * A stream handle is only meaningful inside the HIP runtime instance that created it (a process that loads this library
  * before a framework's bundled copy of the runtime ends up with two instances; load the framework first). */
+/* The stream being replaced should still exist when this is called (the new stream is ordered behind what the old one holds); if it was
+ * destroyed meanwhile the switch still happens, without that ordering. */
 int         yk_set_stream(yk_ctx* c, void* hipStream);
 int         yk_synchronize(yk_ctx* c);
 /* Device-side ordering against another stream of the SAME runtime instance (0 = the null stream), instead of a host fence:

@@ -142,6 +142,10 @@ def test_cpp_lut3d_surface(oracle_built, w, h, seed):
     codes = np.frombuffer(got["yaik_lut_codes"], np.int32).tolist()
     assert codes[0] != 0 and codes[1] == 0, codes                # refused without the LUT, decoded with it
     assert got["yaik_planes_tiled"] == od.planes().tobytes()
+    # crafted '3DTL' headers (a tile count that wraps the 32-bit "colours == 6 * tiles" product; a 3 GB index stream): both refused, with
+    # an error code, before anything is expanded
+    crafted = np.frombuffer(got["yaik_lut_crafted"], np.int32).tolist()
+    assert crafted[0] == 0 and crafted[1] != 0 and crafted[2] == 0 and crafted[3] != 0, crafted
 
 
 @pytest.mark.parametrize("case,n", [("synth512x4", 2), ("synth512x4", 8), ("synth1024x4", 3), ("mixed256x3", 4), ("synth256x4", 6)])

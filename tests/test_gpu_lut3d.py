@@ -219,3 +219,41 @@ def test_lut_round_trip_on_gpu(hip, dec, oracle_built, w, h, seed):
     mse = float(np.mean((rec - planes) ** 2))
     assert 10 * np.log10(255.0 ** 2 / mse) > 35.0
     hip.lut_clear()
+
+
+@pytest.mark.parametrize("cut", ["idx", "tiles"])
+def test_lut_decode_refuses_streams_shorter_than_the_maps_need(hip, dec, oracle_built, cut):
+    """A truncated / crafted '3DTL' chunk: the tile maps claim more tiles or index bytes than the streams hold.  The fill kernel reads the
+    streams at offsets derived from the maps, so the call must be refused (YK_ERR_RANGE) before it runs: no read past a buffer, and the
+    image planes as they were."""
+    from oracle.pyoracle import palette_remap, yko_compress_f
+    from yaik_amd._lib import YaikError
+    pats = bank_patterns()
+    planes = lut_image(128, 128, pats, 31)
+    ora = OracleEncoder(planes)
+    hip.lut_clear()
+    for p in pats:
+        hip.lut_load(p); ora.lut_load(p)
+    hip.set_image(planes)
+    hip.encode(3, False, False)
+    hip.lut_start()
+    for sx, sy in LUT_PASSES:
+        hip.lut_search(sx, sy)
+    s = hip.lut_streams()
+    assert s["tileType"].size > 4
+    colors = palette_remap(yko_compress_f(s["color"], 250), 250)
+    idx = [(s[f"idx{b}"].astype(np.uint16) * 3).astype(np.uint8) for b in (3, 4, 5, 6)]
+    maps = [s[f"map{k}"] for k in range(6)]
+    dec.begin(128, 128)
+    dec.assign_lut(ora.lut_file())
+    before = dec.planes().copy()
+    tiles = s["tileType"]
+    if cut == "idx":
+        f = max(range(4), key=lambda k: idx[k].size)
+        idx[f] = idx[f][: idx[f].size // 2]
+    else:
+        tiles = tiles[: tiles.size // 2]; colors = colors[: tiles.size * 6]
+    with pytest.raises(YaikError):
+        dec.decompress_lut3d(maps, tiles, colors, idx)
+    assert np.array_equal(dec.planes(), before)
+    hip.lut_clear()

@@ -6,6 +6,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
+mkdir -p gpurun_out
 ARGS="--steps 10 --warmup 2 --no-cpu --no-parity"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT.bench.json 2> $OUT.stats.err
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-parity > /dev/null 2> $OUT.pmc1.err

@@ -155,6 +155,8 @@ void yk_destroy(yk_ctx* c) {
     for (int st = 0; st < YK_NUM_STAGES; st++) for (int k = 0; k < YK_STAGE_RING; k++) for (int i = 0; i < 2; i++) if (c->stEv[st][k][i]) (void)hipEventDestroy(c->stEv[st][k][i]);
     if (c->frameGraph) (void)hipGraphExecDestroy(c->frameGraph);
     if (c->evHandoff) (void)hipEventDestroy(c->evHandoff);
+    if (c->evFusedAfter) (void)hipEventDestroy(c->evFusedAfter);
+    if (c->auxStream) (void)hipStreamDestroy(c->auxStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -169,8 +171,10 @@ int yk_set_stream(yk_ctx* c, void* s) {
     // caller queues on the new one: the new stream waits, on the device, for an event recorded on the old stream.
     YK_HIP(c, hipSetDevice(c->device));
     if (!c->evHandoff) YK_HIP(c, hipEventCreateWithFlags(&c->evHandoff, hipEventDisableTiming));
-    YK_HIP(c, hipEventRecord(c->evHandoff, c->stream));
-    YK_HIP(c, hipStreamWaitEvent(next, c->evHandoff, 0));
+    // A caller's stream may be gone by now (the header asks for it to outlive this call, but a handle bound to a dead stream would fail
+    // forever): if the old stream no longer takes an event there is nothing left on it to wait for, and the switch still happens.
+    if (hipEventRecord(c->evHandoff, c->stream) == hipSuccess) YK_HIP(c, hipStreamWaitEvent(next, c->evHandoff, 0));
+    else (void)hipGetLastError();
     c->stream = next;
     return YK_OK;
 }
@@ -423,7 +427,17 @@ int yk_encode_tiles(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst) 
 int yk_order_fused_after(yk_ctx* c, const yk_ctx* other) {
     if (!c || !other) return YK_ERR_BAD_ARG;
     if (c->device != other->device) return yk_fail(c, YK_ERR_BAD_ARG, "yk_order_fused_after: handles of one device");
-    c->fusedAfter = other->evHead ? other->evRing[(other->evHead - 1) % YK_EV_RING][3] : nullptr;
+    c->fusedAfter = nullptr;
+    if (!other->evHead) return YK_OK;
+    // Nothing of `other` is kept beyond this call (it may be destroyed before c encodes again): an auxiliary stream of c waits for the end of
+    // other's fused kernel NOW, while that event certainly exists, and an event of c's own is recorded behind the wait; c's next fused
+    // kernel waits for that one.
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->auxStream) YK_HIP(c, hipStreamCreateWithFlags(&c->auxStream, hipStreamNonBlocking));
+    if (!c->evFusedAfter) YK_HIP(c, hipEventCreateWithFlags(&c->evFusedAfter, hipEventDisableTiming));
+    YK_HIP(c, hipStreamWaitEvent(c->auxStream, other->evRing[(other->evHead - 1) % YK_EV_RING][3], 0));
+    YK_HIP(c, hipEventRecord(c->evFusedAfter, c->auxStream));
+    c->fusedAfter = c->evFusedAfter;
     return YK_OK;
 }
 

@@ -84,7 +84,8 @@ struct yk_ctx {
     uint32_t* totals = nullptr;         // [3][2] device
     unsigned long long* exportSizes = nullptr;   // [16] total + section sizes of the last yk_export_tile_maps
     hipEvent_t evHandoff = nullptr;              // yk_stream_handoff / yk_stream_wait_for
-    hipEvent_t fusedAfter = nullptr;             // yk_order_fused_after: the next fused kernel waits for this event (another handle's)
+    hipEvent_t fusedAfter = nullptr;             // yk_order_fused_after: the next fused kernel waits for this event (= evFusedAfter, never another handle's)
+    hipEvent_t evFusedAfter = nullptr; hipStream_t auxStream = nullptr;   // this handle's own: the event behind a wait for the other handle's fused kernel
     uint16_t* defsOut = nullptr;        // [3][T8]
     uint8_t*  nibOut = nullptr;         // [3][T8*32 + 8]
     size_t nibStride = 0;

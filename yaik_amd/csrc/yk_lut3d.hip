@@ -861,6 +861,7 @@ int yk_decode_lut3d(yk_ctx* c, const uint8_t* const maps[6], const size_t mapByt
         if (e == hipSuccess && idxBytes[f]) e = hipMemcpyAsync(dIdx[f], idx[f], idxBytes[f], hipMemcpyHostToDevice, c->stream);
     }
     unsigned long long tileBase = 0, ib[4] = { 0, 0, 0, 0 };
+    bool shortStream = false;
     for (int k = 0; k < 6 && e == hipSuccess; k++) {
         if (!maps[k] || !mapBytes[k]) continue;
         const LutGeo g = yk_lut_geo(sz[k][0], sz[k][1], w);
@@ -877,22 +878,28 @@ int yk_decode_lut3d(yk_ctx* c, const uint8_t* const maps[6], const size_t mapByt
                    c->lutDec->tbl[0], c->lutDec->tbl[1], c->lutDec->tbl[2], c->lutDec->tbl[3], c->lutDec->nPat, c->dPlanes, c->dPlaneSize, w >> 3, c->dTile4, (w + 15) >> 4
         hipLaunchKernelGGL(yk_dl_tile_kernel<false>, dim3((unsigned)nb), dim3(1024), 0, c->stream, YK_DL_ARGS);
         for (int f = 0; f < 4; f++) hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, byteSums + f * nb, (int)nb, totals + 1 + f);
-        hipLaunchKernelGGL(yk_dl_tile_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, YK_DL_ARGS);
-#undef YK_DL_ARGS
-        hipLaunchKernelGGL(yk_dl_mark_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, c->stream, dMap, nSlots, g, w, h, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
+        // The counting launch and the scans know what this pass would consume: tiles / colours and index bytes per depth.  The fill reads the
+        // streams at those offsets, so an (untrusted) chunk whose streams are shorter than its maps claim is refused HERE, before anything
+        // is read past a buffer or written into the image planes.
         e = hipGetLastError();
         uint32_t tot[5] = {};
         if (e == hipSuccess) e = hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        unsigned long long used = tot[0];
-        if (tileBase + used > nTiles) used = nTiles - tileBase;
-        tileBase += used;
+        if (e != hipSuccess) break;
+        bool fits = tileBase + tot[0] <= nTiles;
+        for (int f = 0; f < 4; f++) fits = fits && (ib[f] + tot[1 + f] <= idxBytes[f]);
+        if (!fits) { shortStream = true; break; }
+        hipLaunchKernelGGL(yk_dl_tile_kernel<true>, dim3((unsigned)nb), dim3(1024), 0, c->stream, YK_DL_ARGS);
+#undef YK_DL_ARGS
+        hipLaunchKernelGGL(yk_dl_mark_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, c->stream, dMap, nSlots, g, w, h, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
+        e = hipGetLastError();
+        tileBase += tot[0];
         for (int f = 0; f < 4; f++) ib[f] += tot[1 + f];
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     freeAll();
     if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "3-D LUT decode", e);
-    for (int f = 0; f < 4; f++) if (ib[f] > idxBytes[f]) return yk_fail(c, YK_ERR_RANGE, "index stream shorter than the tile maps need");
+    if (shortStream) return yk_fail(c, YK_ERR_RANGE, "tile, colour or index stream shorter than the tile maps need");
     if (consumed) { consumed[0] = (size_t)tileBase * 2; consumed[1] = (size_t)tileBase * 6; for (int f = 0; f < 4; f++) consumed[2 + f] = (size_t)ib[f]; }
     return YK_OK;
 }

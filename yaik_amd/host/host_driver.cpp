@@ -13,6 +13,7 @@
 // YAIK_* decoder API, the way an application would use the two libraries.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <unistd.h>
@@ -166,6 +167,33 @@ static int run_lut(EncoderContext* ctx, Image* img, int w, int h, int np, const 
     codes[1] = decodeOnce();
     blob("yaik_lut_codes", codes, sizeof codes);
     blob("yaik_planes_tiled", tiled.data(), tiled.size());
+    {   // a crafted '3DTL' header: tile count 0x80000001 with colour count 6 passes a 32-bit "colours == 6 * tiles" test (the product wraps);
+        // truncated counts must be refused with YAIK_INVALID_STREAM before anything is expanded or handed to the GPU
+        int neg[4] = { -1, -1, -1, -1 };
+        const u8* bytes = reinterpret_cast<const u8*>(stream.data());
+        size_t at = 12;                                               // first chunk behind the 12-byte file header
+        while (at + 8 <= (size_t)n) {
+            u32 tag, len; memcpy(&tag, bytes + at, 4); memcpy(&len, bytes + at + 4, 4);
+            if (tag == 0x4c544433u) break;                            // '3DTL'
+            at += 8 + (((size_t)len + 3) & ~(size_t)3);
+        }
+        if (at + 8 + 76 <= (size_t)n) {
+            std::vector<u32> bad(stream);
+            u8* hb = reinterpret_cast<u8*>(bad.data()) + at + 8;
+            const u32 colorCnt = 6, typeCnt = 0x80000001u;
+            memcpy(hb, &colorCnt, 4); memcpy(hb + 4, &typeCnt, 4);
+            bool pre = YAIK_DecodeImagePre(lib, bad.data(), (u32)n, &di);
+            di.outputImage = outImg.data(); di.outputImageStride = di.width * 4;
+            neg[0] = (pre && YAIK_DecodeImage(bad.data(), (u32)n, &di)) ? 1 : 0; neg[1] = (int)YAIK_GetErrorCode();
+            std::vector<u32> bad2(stream);                            // an index stream that claims to be 3 GB long
+            u8* hb2 = reinterpret_cast<u8*>(bad2.data()) + at + 8;
+            const u32 huge = 0xC0000000u; memcpy(hb2 + 8, &huge, 4);
+            pre = YAIK_DecodeImagePre(lib, bad2.data(), (u32)n, &di);
+            di.outputImage = outImg.data(); di.outputImageStride = di.width * 4;
+            neg[2] = (pre && YAIK_DecodeImage(bad2.data(), (u32)n, &di)) ? 1 : 0; neg[3] = (int)YAIK_GetErrorCode();
+        }
+        blob("yaik_lut_crafted", neg, sizeof neg);
+    }
     YAIK_Release(lib);
     return 0;
 }

@@ -189,19 +189,26 @@ bool YAIK_DecodeImage(void* stream, uint32_t length, YAIK_SDecodedImage* info) {
                 if (hb.length < sizeof(HeaderTile3D)) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
                 if (!gLib->hasLut) { setError(YAIK_INVALID_LUT); bad = true; break; }                       // the reference would read a NULL table here
                 HeaderTile3D th; memcpy(&th, body, sizeof th);
+                // The counts come from an untrusted stream: all size arithmetic in 64 bits, and nothing is expanded before the counts are
+                // plausible (a tile is at least 4x4 pixels; six colour bytes per tile; the reference leaves both checks a TODO, :1079).
+                const uint64_t maxTiles = (uint64_t)(w / 4) * (uint64_t)(h / 4);
+                if ((uint64_t)th.streamTypeCnt > maxTiles || (uint64_t)th.streamColorCnt != 6ull * (uint64_t)th.streamTypeCnt) { setError(YAIK_INVALID_STREAM); bad = true; break; }
                 const uint8_t* q = body + sizeof th;
                 const uint32_t cmp[12] = { th.compr3BitSize, th.compr4BitSize, th.compr5BitSize, th.compr6BitSize, th.comprTypeSize, th.comprColorSize,
                                            th.sizeT16_8MapCmp, th.sizeT8_16MapCmp, th.sizeT8_8MapCmp, th.sizeT8_4MapCmp, th.sizeT4_8MapCmp, th.sizeT4_4MapCmp };
                 const uint32_t raw[12] = { th.stream3BitCnt, th.stream4BitCnt, th.stream5BitCnt, th.stream6BitCnt, th.streamTypeCnt * 2, th.streamColorCnt,
                                            th.sizeT16_8Map, th.sizeT8_16Map, th.sizeT8_8Map, th.sizeT8_4Map, th.sizeT4_8Map, th.sizeT4_4Map };
                 std::vector<uint8_t> part[12];
+                const uint64_t maxStream = (uint64_t)w * (uint64_t)h * 3 + 4096;                            // no stream of an image can be longer than its pixels
+                for (int k = 0; k < 12 && !bad; k++) if ((uint64_t)raw[k] > maxStream) { setError(YAIK_INVALID_STREAM); bad = true; }
                 for (int k = 0; k < 12 && !bad; k++) {
-                    if (q + cmp[k] > endBlock) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
+                    if ((uint64_t)cmp[k] > (uint64_t)(endBlock - q)) { setError(YAIK_INVALID_TAG_ID); bad = true; break; }
                     if (raw[k] && !zexpand(q, cmp[k], raw[k], part[k], 256)) { bad = true; break; }
                     q += cmp[k];
                 }
                 if (bad) break;
-                if (th.streamColorCnt != th.streamTypeCnt * 6) { setError(YAIK_INVALID_STREAM); bad = true; break; }      // the reference leaves this a TODO (:1079)
+                // what yk_decode_lut3d may read is what was really expanded, not what the header claims
+                if (part[4].size() < (size_t)th.streamTypeCnt * 2 || part[5].size() < (size_t)th.streamTypeCnt * 6) { setError(YAIK_INVALID_STREAM); bad = true; break; }
                 if (th.streamColorCnt) PaletteFullRangeRemapping(part[5].data(), (int)th.streamColorCnt, th.compressionRateColor);
                 const uint8_t* maps[6]; size_t mapBytes[6]; const uint8_t* idx[4]; size_t idxBytes[4]; size_t used[6];
                 for (int k = 0; k < 6; k++) { maps[k] = raw[6 + k] ? part[6 + k].data() : nullptr; mapBytes[k] = raw[6 + k]; }
