@@ -130,6 +130,45 @@ def test_c5_16384_rgba_stripes_and_decode_round_trip(hip):
         assert total == wnn and np.array_equal(cat, wn)
 
 
+def test_c5_16384_rgba_bit_exact_against_the_oracle(hip, oracle_built):
+    """configs[4] at full size against the CPU oracle itself (not only through properties): the alpha tile-reject bitmap and bounds, the seven
+    tile bitmaps and, per plane, tile definitions and nibble stream of the 16384x16384 RGBA frame -- the oracle takes one host core for about
+    a minute on it, the GPU encode runs meanwhile."""
+    import hashlib
+    import threading
+    from oracle.pyoracle import PASSES, OracleEncoder
+    from yaik_amd.synth import synth_planes_torch
+    W = 16384
+    planes = synth_planes_torch(W, n_planes=4, device="cuda")
+    host = planes.cpu().numpy()
+    want = {}
+
+    def run_oracle():                                        # ctypes releases the GIL inside the C restatement
+        ora = OracleEncoder(host)
+        want["mip"] = ora.mip_prefilter()
+        want["bitmaps"] = [hashlib.sha256(ora.fitting_quad_smooth(sx, sy)[1].tobytes()).hexdigest() for sx, sy in PASSES]
+        want["range"] = []
+        for p in range(3):
+            d, nb, nn, _ = ora.dynamic_tile_encode(p, False)
+            want["range"].append((hashlib.sha256(d.tobytes()).hexdigest(), hashlib.sha256(nb.tobytes()).hexdigest(), int(nn)))
+    th = threading.Thread(target=run_oracle)
+    th.start()
+    hip.set_image(planes)
+    a = hip.mip_prefilter()
+    hip.encode(3, False, False)
+    got_bm = [hashlib.sha256(hip.gradient_bitmap(i).tobytes()).hexdigest() for i in range(7)]
+    got_rng = []
+    for p in range(3):
+        d, nb, nn = hip.range_streams(p)
+        got_rng.append((hashlib.sha256(d.tobytes()).hexdigest(), hashlib.sha256(nb.tobytes()).hexdigest(), int(nn)))
+    th.join()
+    m = want["mip"]
+    assert bool(a["has_chunk"]) == bool(m["has_chunk"]) and np.array_equal(a["bounds"], m["bounds"]) and int(a["remaining"]) == int(m["remaining"])
+    assert np.array_equal(a["tile_bbox"], m["tile_bbox"]) and np.array_equal(a["bitmap"], m["bitmap"])
+    assert got_bm == want["bitmaps"]
+    assert got_rng == want["range"]
+
+
 @pytest.mark.parametrize("wh,npl", [((72, 40), 3), ((200, 136), 3), ((128, 128), 4)])
 def test_export_layout_on_small_and_odd_tile_grids(hip, wh, npl):
     """yk_export_tile_maps (one packing kernel) on tile grids whose per-plane sections are not 16-byte aligned in HBM"""
