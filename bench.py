@@ -3,9 +3,10 @@
 8x8 4-bpp range quantiser of 3 planes) on an 8192x8192 RGBA frame of synthetic "YAIK-synth v1" data, inputs resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--mode3] [--in-flight F] [--no-cpu] [--no-parity]
-                  [--stage encode|corners|range1d|decode] [--layout frames|stripes]
+                  [--stage encode|all|corners|range1d|decode|lut3d] [--layout frames|stripes]
 
-Default (--stage encode --layout frames) is the headline line described below.  --stage corners | range1d | decode time the other
+Default (--stage encode --layout frames) is the headline line described below.  --stage all = every GPU stage of ConvertHotPath per frame
+(encode + corner streams + live 1-D range path) with frames in flight; --stage corners | range1d | decode | lut3d time the other
 stages of the path on the same frame (corner-colour streams, live 1-D range path, GPU decode) and print a `roofline` for the
 stage's dominant kernel; --layout stripes (N > 1) encodes ONE image as row stripes: stripe bbox all-reduce, one RCCL gather of the
 tile maps, checked against a whole-image encode on rank 0 (strong scaling).
@@ -146,24 +147,22 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
     if args.stage == "corners":
         lat = (W // 4 + 1) ** 2
         nb = sum(enc.gradient_corners(i).size for i in range(7))
-        alg = bitmap_bytes + 4 * lat * 2 + 4 * nb            # bitmaps read + lattice owner cleared and resolved (4 B per point, twice) + 3 B read as 3 samples (12 B) / 3 B written per colour
-        alg = bitmap_bytes + 8 * lat + 5 * nb
-        kname, kms, note = "yk_corner_* (lattice clear + owner + count + scan + emit, 7 passes)", per[0], "sparse scatter / gather: latency- and atomics-bound, far from the HBM roof by construction"
+        alg = bitmap_bytes + 8 * lat + 5 * nb                # bitmaps read + lattice owner cleared and resolved (4 B per point, twice) + per colour byte: 4 B sample read, 1 B written
+        kname, kms, note, bound = "yk_corner_* (lattice clear + owner + count + scan + emit, 7 passes)", per[0], "sparse scatter / gather: latency- and atomics-bound, far from the HBM roof by construction", "latency"
     elif args.stage == "range1d":
         pixn = uncovered * 3
         alg = 12 * W * W + pixn + 64 * 0 + (W // 8) * (W // 8) * 3 * 3     # three int32 planes read once + 1 B per uncovered pixel and plane + 3 parameter bytes per tile-plane
-        kname, kms, note = "yk_range1d_kernel", per[1], f"scan + pack kernels: {per[2]:.4f} ms per frame on top"
+        kname, kms, note, bound = "yk_range1d_kernel", per[1], f"scan + pack kernels: {per[2]:.4f} ms per frame on top", "hbm"
     elif args.stage == "lut3d":
         cand = int((~cov).sum()) * 16                         # pixels of tiles with anything left to code, an upper bound of what the passes read
         alg = 12 * cand * 6                                   # every pass reads the three int32 samples of its candidate tiles' pixels once
-        kname, kms = "yk_lut_search_kernel (6 tile shapes)", per[6]
+        kname, kms, bound = "yk_lut_search_kernel (6 tile shapes)", per[6], "valu"
         note = (f"VALU-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations x 8 points squared distances (v_dot4_i32_i8) per candidate tile; "
                 f"{lut_matched[0]} tiles matched on this frame; algorithmic bytes = the candidate tiles' samples once per pass")
     else:
         pixn = uncovered * 3
-        alg = pixn + 3 * W * W                              # yk_dec1d_kernel: 1 B per uncovered pixel and plane read + the pixels it writes (<= 3 B/pixel); the dominant decode kernel by bytes
-        alg = 2 * pixn + (W // 8) * (W // 8) * 9
-        kname, kms = "yk_dec1d_kernel (+ count / scan kernels)", per[4]
+        alg = 2 * pixn + (W // 8) * (W // 8) * 9             # yk_dec1d_kernel: 1 B per uncovered pixel and plane read, the same written, 3 parameter bytes per tile-plane
+        kname, kms, bound = "yk_dec1d_kernel (+ count / scan kernels)", per[4], "hbm"
         note = (f"other decode kernels per frame: gradient owner/corner/render x{ms[3][1] // max(1, args.steps)} passes {per[3]:.4f} ms, "
                 f"yk_dec_detile_kernel {per[5]:.4f} ms (6 B/pixel moved = {6 * W * W / (per[5] * 1e-3) / 1e9 if per[5] > 0 else 0:.0f} GB/s)")
     achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -175,8 +174,120 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         "config": {"workload": f"{W}x{W} RGBA frame per GPU, stage '{args.stage}' of the tile path after a full encode; a step is one call sequence through the "
                                "C-ABI incl. its host-side part (decode: host streams in, interleaved RGB image out over PCIe)",
                    "parallelism": f"replicas x{world} (no collective)" if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        # `bound` names what limits the stage's dominant kernel; achieved / frac are its algorithmic bytes against the HBM figure either way
+        # (for a latency- or VALU-bound kernel that fraction says how far from a byte-bound kernel it is, not how well it is tuned)
+        "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": kname, "kernel_ms": round(kms, 4), "algorithmic_bytes": int(alg), "note": note},
+    }
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_all(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
+    """--stage all: everything the GPU does for a frame of ConvertHotPath, frames in flight on --in-flight handles (default 3):
+        alpha tile-reject -> fused gradient / range kernel -> stream compaction -> the seven corner-colour streams (a6 rgbStream) ->
+        the live 1-D range path (a15, its scan + pack).
+    No call in the loop waits on the host (the corner / 1-D stream lengths stay on the device until someone reads a stream); the fused kernels
+    of the frames take turns, and the memory-bound helper stages of one frame (alpha, compaction, corners: atomics / latency, 1-D: HBM) run
+    under the VALU-bound fused kernel of another.  N > 1: replicas (these stages shard like the encode)."""
+    import numpy as np
+    import torch
+    from yaik_amd._lib import lib
+    from yaik_amd.encoder import HipTileEncoder, _chk
+    from yaik_amd.synth import synth_planes_torch
+    W = args.size
+    K = max(1, args.in_flight if args.in_flight != 2 else 3)
+    frames = [synth_planes_torch(W, n_planes=4, seed=12345 + rank * K + j, device=dev) for j in range(K)]
+    torch.cuda.synchronize()
+    encs = [HipTileEncoder(dev_index) for _ in range(K)]
+    for e, f in zip(encs, frames):
+        e.set_image(f)
+    L = lib()
+    ordered = K > 1 and not args.free_overlap and W * W >= 8192 * 8192
+
+    def step():
+        for j, e in enumerate(encs):
+            if ordered:
+                e.order_fused_after(encs[j - 1])
+            e.alpha_reject()
+            e.alpha_finish(None)
+            e.encode(3, args.mode3, False)
+            e.gradient_corners_run()
+            _chk(e._h, L.yk_range1d_encode(e._h))
+
+    def fence():
+        torch.cuda.synchronize()
+        for e in encs:
+            e.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    for e in encs:
+        e.kernel_ms()
+        for st in (0, 1, 2):
+            e.stage_ms(st)
+    kms = {"encode": 0.0, "alpha": 0.0, "pack": 0.0}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+        if (i + 1) % 32 == 0 or i + 1 == args.steps:
+            done = (i % 32) + 1
+            for e in encs:
+                k = e.kernel_ms()
+                for n in kms:
+                    kms[n] += k[n] * done / len(encs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for n in kms:
+        kms[n] /= max(1, args.steps)
+    st = {s_: [0.0, 0] for s_ in (0, 1, 2)}
+    for e in encs:
+        for s_ in st:
+            m = e.stage_ms(s_)
+            st[s_][0] += m[0]; st[s_][1] += m[1]
+    per = {s_: (st[s_][0] / st[s_][1] if st[s_][1] else 0.0) for s_ in st}   # mean interval of the stage's kernels per frame (sharing the chip)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    enc = encs[0]
+    # algorithmic bytes of the whole path per frame: SURVEY 8(d) for the encode (four int32 planes read once + bitmaps + definitions + nibbles)
+    # + the corner streams written + the 1-D path's planes read once more, its pixel bytes and 3 parameter bytes per coded tile-plane
+    nd_nn = [enc.range_streams(p) for p in range(3)]
+    bitmap_bytes = sum(enc.gradient_bitmap(p).size for p in range(7))
+    out_bytes = sum(2 * d.size + nb.size for d, nb, _ in nd_nn)
+    corner_bytes = sum(enc.gradient_corners(i).size for i in range(7))
+    pix, typ = enc.dynamic_tile_compressor()
+    alg = 16 * W * W + bitmap_bytes + out_bytes + corner_bytes + 12 * W * W + pix.size + typ.size
+    ms_frame = elapsed / args.steps * 1e3 / K
+    roof = measured_copy_roof(dev)
+    achieved = alg / (ms_frame * 1e-3) / 1e9
+    result = {
+        "metric": "Mpix/s whole tile path on the GPU (alpha reject + fused gradient/range kernel + compaction + corner streams + 1-D range path), 8K RGBA"
+                  if W == 8192 else f"Mpix/s whole tile path on the GPU, {W}x{W} RGBA",
+        "value": round(W * W * world * K * args.steps / 1e6 / elapsed, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/int32 (+f32 mode-selection sums)", "data": "synthetic (YAIK-synth v1, seed 12345+rank)",
+        "config": {"workload": f"{W}x{W} RGBA frame per GPU, every GPU stage of ConvertHotPath, inputs resident in HBM, outputs left in HBM",
+                   "frames_per_step": world * K, "frames_in_flight_per_gpu": K, "ms_per_frame": round(ms_frame, 4),
+                   "parallelism": f"replicas x{world} (no collective)" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "peak_measured": round(roof, 1), "frac_of_measured": round(achieved / roof, 4), "traffic": None,
+                     "kernel": "whole path (all kernels of a frame; time = wall clock per frame with the frames in flight)", "kernel_ms": round(ms_frame, 4),
+                     "algorithmic_bytes": int(alg),
+                     "stages_ms_per_frame": {"fused yk_encode2_kernel": round(kms["encode"], 4), "alpha": round(kms["alpha"], 4), "scan+pack": round(kms["pack"], 4),
+                                             "corner streams": round(per[0], 4), "1-D range kernel": round(per[1], 4), "1-D scan+pack": round(per[2], 4)},
+                     "note": "stage intervals are event-timed on each frame's stream and include the time a stage shares the chip with other frames' kernels; "
+                             "whole-path ms per frame minus the fused kernel = what the helper stages could not hide"},
     }
     print(json.dumps(result))
     if world > 1:
@@ -452,7 +563,7 @@ def main() -> int:
                     "the form for batches of small frames (BASELINE config 4: --size 2048 --batch 32); a step = that many frames per GPU")
     ap.add_argument("--graph", action="store_true", help="launch every frame as one replayed hipGraph (yk_encode_frame): for batches of small "
                     "frames, where the ~8 stream operations per frame are what limits the rate; per-kernel times are then one interval")
-    ap.add_argument("--stage", choices=["encode", "corners", "range1d", "decode", "lut3d"], default="encode", help="which stage of the path a step runs: encode = the "
+    ap.add_argument("--stage", choices=["encode", "all", "corners", "range1d", "decode", "lut3d"], default="encode", help="which stage of the path a step runs: encode = the "
                     "headline (alpha reject + fused gradient/range kernel + compaction); corners = the seven corner-colour streams (a6 rgbStream); "
                     "range1d = the live 1-D range path (a15); decode = gradient + 1-D decode + de-tile on the GPU (a16, a17, a20); lut3d = the 3-D LUT tile search "
                     "(f4) on a synthetic bank, after an encode")
@@ -500,6 +611,8 @@ def main() -> int:
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.stage == "all":
+        return bench_all(args, rank, world, dist, dev, dev_index, comm_dev)
     if args.stage != "encode":
         return bench_stage(args, rank, world, dist, dev, dev_index, comm_dev)
     if args.layout == "stripes":

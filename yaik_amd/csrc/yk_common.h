@@ -98,6 +98,8 @@ struct yk_ctx {
     uint32_t* cornerEdgeIdx = nullptr;  // [2][w/4+1]: emission index (in corners, within its pass) of the first / last lattice row
     bool cornersReady = false; int nextCornerPass = 0;
     size_t cornerOff[7] = {}, cornerBytes[7] = {};
+    const uint32_t* cornerTotalsDev = nullptr; bool cornerTotalsPending = false;   // stream lengths still on the device (yk_corners_finish)
+    const uint32_t* r1TotalsDev = nullptr; bool r1TotalsPending = false;           // the same for the 1-D path (yk_range1d_finish)
     // partial-plane gradient passes (FittingQuadSmooth with nullable planes): per-plane coverage (mapSmoothTile[p], u16 per 16x16 tile, bit = cell)
     // and per-plane "corner already emitted" flags per lattice point (mappedRGB[p]); allocated by the first partial pass after an encode
     uint16_t* covCh = nullptr; size_t covChStride = 0;     // [3][covChStride]
@@ -150,6 +152,7 @@ int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox);
 int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst, bool batch = false);
 int yk_launch_pack(yk_ctx* c, bool batch = false);
 int yk_launch_corners(yk_ctx* c);
+int yk_corners_finish(yk_ctx* c);                         // reads the corner streams' lengths back if that is still pending (synchronises)
 void yk_lut_dec_destroy(yk_ctx* c);
 void yk_lut_destroy(yk_ctx* c);                          // frees the 3-D LUT bank and streams (yk_lut3d.hip)
 int yk_pp_activate(yk_ctx* c);                           // per-plane coverage / corner flags for the passes behind the RGB passes

@@ -258,11 +258,21 @@ int yk_launch_corners(yk_ctx* c) {
                        c->plane[0], c->plane[1], c->plane[2], c->strideElems, c->cornerStream, region, c->cornerEdgeIdx, latH, c->h + c->halo);
     YK_HIP(c, hipGetLastError());
     { int rc = yk_stage_end(c, YK_STAGE_CORNERS); if (rc) return rc; }
-    uint32_t totals[7];
-    YK_HIP(c, hipMemcpyAsync(totals, totalDev, sizeof totals, hipMemcpyDeviceToHost, c->stream));
-    YK_HIP(c, hipStreamSynchronize(c->stream));
-    for (int p = 0; p < 7; p++) { c->cornerOff[p] = region * p; c->cornerBytes[p] = (size_t)totals[p] * 3; }
+    // the stream lengths stay on the device until somebody asks for a stream (yk_corners_finish): a caller that keeps frames in flight
+    // (bench.py --stage all, the C++ mirror's pipelined conversion) is not stopped here
+    for (int p = 0; p < 7; p++) c->cornerOff[p] = region * p;
+    c->cornerTotalsDev = totalDev; c->cornerTotalsPending = true;
     c->cornersReady = true;
+    return YK_OK;
+}
+
+int yk_corners_finish(yk_ctx* c) {
+    if (!c->cornerTotalsPending) return YK_OK;
+    uint32_t totals[7];
+    YK_HIP(c, hipMemcpyAsync(totals, c->cornerTotalsDev, sizeof totals, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < 7; p++) c->cornerBytes[p] = (size_t)totals[p] * 3;
+    c->cornerTotalsPending = false;
     return YK_OK;
 }
 
@@ -271,6 +281,7 @@ extern "C" int yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t
     if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
     YK_HIP(c, hipSetDevice(c->device));
     if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
+    { int rc = yk_corners_finish(c); if (rc) return rc; }
     if (nBytes) *nBytes = c->cornerBytes[pass];
     if (hostOut) {
         if (cap < c->cornerBytes[pass]) return yk_fail(c, YK_ERR_RANGE, "corner buffer too small");

@@ -215,10 +215,9 @@ int yk_range1d_encode(yk_ctx* c) {
                            -1, (const uint32_t*)nullptr);
         YK_HIP(c, hipGetLastError());
         { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
-        YK_HIP(c, hipMemcpyAsync(t, tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
-        YK_HIP(c, hipStreamSynchronize(c->stream));
-        for (int p = 0; p < 3; p++) { c->r1EndTiles[p] = t[0] * (p + 1); c->r1EndPix[p] = t[1] * (p + 1); }
-        t[0] *= 3; t[1] *= 3;
+        // the totals stay on the device until a getter needs them (yk_range1d_finish): callers that keep frames in flight are not stopped here
+        c->r1TotalsDev = tot; c->r1TotalsPending = true; c->r1Ready = true;
+        return YK_OK;
     } else {
         // partial-plane passes ran: every plane has its own coverage, so its own counts, scans and stream offsets
         uint32_t* runBase = tot + 4;                                         // [4][2]: (tile-planes, pixel bytes) before plane p; [3] = totals
@@ -241,13 +240,25 @@ int yk_range1d_encode(yk_ctx* c) {
         for (int p = 0; p < 3; p++) { c->r1EndTiles[p] = ends[2 * p + 2]; c->r1EndPix[p] = ends[2 * p + 3]; }
         t[0] = ends[6]; t[1] = ends[7];
     }
-    c->r1Tiles = t[0]; c->r1PixCount = t[1]; c->r1Ready = true;          // tile-planes coded and pixel bytes, all three planes
+    c->r1Tiles = t[0]; c->r1PixCount = t[1]; c->r1Ready = true; c->r1TotalsPending = false;   // tile-planes coded and pixel bytes, all three planes
+    return YK_OK;
+}
+
+static int yk_range1d_finish(yk_ctx* c) {
+    if (!c->r1TotalsPending) return YK_OK;
+    uint32_t t[2];
+    YK_HIP(c, hipSetDevice(c->device));
+    YK_HIP(c, hipMemcpyAsync(t, c->r1TotalsDev, sizeof t, hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < 3; p++) { c->r1EndTiles[p] = t[0] * (p + 1); c->r1EndPix[p] = t[1] * (p + 1); }
+    c->r1Tiles = t[0] * 3; c->r1PixCount = t[1] * 3; c->r1TotalsPending = false;
     return YK_OK;
 }
 
 int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]) {
     if (!c) return YK_ERR_BAD_ARG;
     if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");
+    { int rc = yk_range1d_finish(c); if (rc) return rc; }
     for (int p = 0; p < 3; p++) { if (pixEnd) pixEnd[p] = c->r1EndPix[p]; if (typeEnd) typeEnd[p] = (size_t)c->r1EndTiles[p] * 3; }
     return YK_OK;
 }
@@ -255,6 +266,7 @@ int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]) {
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType) {
     if (!c) return YK_ERR_BAD_ARG;
     if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");
+    { int rc = yk_range1d_finish(c); if (rc) return rc; }
     const size_t np = (size_t)c->r1PixCount, nt = (size_t)c->r1Tiles * 3;
     if (nPix) *nPix = np;
     if (nType) *nType = nt;
