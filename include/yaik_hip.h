@@ -312,28 +312,6 @@ int yk_decode_tile4x4(yk_ctx* c, uint8_t* hostOut, size_t cap);
 /* the three planes of tile4x4Mask back to back (planes 1 and 2 are meaningful once a partial-plane pass has split the masks) */
 int yk_decode_tile4x4_planes(yk_ctx* c, uint8_t* hostOut, size_t cap);
 
-/* ---- self tests of the arithmetic shortcuts the kernels rely on (exhaustive, run on the device) ----------------
- * which = 0: reciprocal+FMA division == IEEE division for every (minDiff 0..255, value 1..256) pair; *result = mismatches
- * which = 1: floor((n + 0.5) * rcp(scale)) == n / scale for DiffRangeEncode's operands (EncoderContext.cpp:604-623)
- * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391)
- * which = 3: the quantiser table of the fused kernel: for every (min, max) of a tile the LUTs of DynamicTile::buildTable
- *            (EncoderContext.cpp:625-699) equal BN + K[rangeDecode], and every value in [min, max] finds in the table the index
- *            and minDiff the first-minimum scan of GetTileDynamic_Y (:873-881) finds in those LUTs */
-int yk_selftest(yk_ctx* c, int which, int* result);
-/* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
- * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the nearest-entry lookups (table gathers; LUT search in
- * the first-generation kernel), 8 = skip the error sums (first-generation kernel).
- * One flag only selects a code path and leaves the results exact (used by the parity tests): 16 = re-sum every tile in the
- * reference's sequential order. */
-int yk_set_ablation(yk_ctx* c, int flags);
-/* which implementation of the fused kernel yk_encode_tiles launches: 2 (default) = the library's kernel (lane per 4x4 cell); 1 = an
- * external cross-check implementation registered with yk_set_cross_check_launcher (the test suite's first-generation kernel,
- * tests/csrc/yk_encode_v1.hip: lane per pixel row).  Without a registered launcher version 1 fails with YK_ERR_STATE at encode time. */
-int yk_set_kernel_version(yk_ctx* c, int version);
-/* test hook: fn = int (*)(hipStream_t stream, const YkEncodeParams* params) (yaik_amd/csrc/yk_common.h), launching a kernel that fills the
- * same per-tile outputs from the same parameters; NULL unregisters.  Process-wide. */
-int yk_set_cross_check_launcher(void* fn);
-
 /* ---- timing hooks for bench.py: HIP events on the handle's stream around every alpha stage / fused kernel / compaction.
  * Returns the averages over the yk_encode_tiles calls since the previous query (a ring of 64 event sets, older ones are
  * dropped), so a caller can queue many frames back to back and read the per-kernel times once, without a sync per frame.

@@ -55,19 +55,24 @@ def compare_encode(planes: np.ndarray, hip, mode3bit_only: bool, want_dst: bool 
     return bad
 
 
-def select_kernel_version(enc, version: int) -> None:
-    """version 2 = the library's fused kernel; 1 = the test suite's independent first-generation implementation
-    (tests/csrc/libyaik_v1check.so, built by yaik_amd/csrc/Makefile), handed to the library through its cross-check hook."""
+def encoder_for_kernel_version(version: int, device: int = 0):
+    """version 2 = the PRODUCT library's fused kernel (yaik_amd/libyaik_hip.so, no hooks involved); 1 = the test suite's independent
+    first-generation implementation (tests/csrc/libyaik_v1check.so), registered with the TEST build of the library
+    (tests/csrc/libyaik_hip_test.so, include/yaik_hip_test.h) through its cross-check hook."""
     import ctypes as C
     import os
-    from yaik_amd._lib import lib
-    if version == 1:
-        here = os.path.dirname(os.path.abspath(__file__))
-        path = os.path.join(here, "csrc", "libyaik_v1check.so")
-        if not os.path.exists(path):                                       # normally built by __graft_entry__.build() / make -C yaik_amd/csrc
-            import subprocess
-            subprocess.run(["make", "-C", os.path.join(os.path.dirname(here), "yaik_amd", "csrc")], check=True)
-        v1 = C.CDLL(path)
-        select_kernel_version._keep = v1                                   # the library keeps a raw function pointer
-        assert lib().yk_set_cross_check_launcher(C.cast(v1.yk_v1_launch, C.c_void_p)) == 0
-    assert lib().yk_set_kernel_version(enc._h, version) == 0
+    from yaik_amd._lib import test_lib
+    from yaik_amd.encoder import HipTileEncoder
+    if version == 2:
+        return HipTileEncoder(device)
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "csrc", "libyaik_v1check.so")
+    if not os.path.exists(path):                                           # normally built by __graft_entry__.build() / make -C yaik_amd/csrc
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(os.path.dirname(here), "yaik_amd", "csrc")], check=True)
+    v1 = C.CDLL(path)
+    encoder_for_kernel_version._keep = v1                                  # the library keeps a raw function pointer
+    enc = HipTileEncoder(device, hooks=True)
+    assert test_lib().yk_set_cross_check_launcher(C.cast(v1.yk_v1_launch, C.c_void_p)) == 0
+    assert test_lib().yk_set_kernel_version(enc._h, 1) == 0
+    return enc

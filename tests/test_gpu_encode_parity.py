@@ -12,11 +12,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module", params=[2, 1], ids=["kernel_v2", "kernel_v1"])
 def hip(request):
     """Both implementations of the fused kernel (lane per 4x4 cell / lane per pixel row) must match the oracle."""
-    from yaik_amd._lib import lib
-    from yaik_amd.encoder import HipTileEncoder
-    e = HipTileEncoder(0)
-    from tests.parity import select_kernel_version
-    select_kernel_version(e, request.param)
+    from tests.parity import encoder_for_kernel_version
+    e = encoder_for_kernel_version(request.param)
     yield e
     e.close()
 
@@ -87,14 +84,13 @@ def test_gpu_outputs_match_reference_hashes(oracle_built, name):
 def test_exact_resummation_path_bit_exact(oracle_built, case):
     """kernel v2 screens the mode-selection sums in tree order and falls back to the reference's sequential order only
     for ambiguous tiles; flag 16 forces that fallback for every tile, and the result must still be bit-exact."""
-    from yaik_amd._lib import lib
+    from yaik_amd._lib import test_lib
     from yaik_amd.encoder import HipTileEncoder
     planes = {"synth256x4": lambda: synth_planes(256, n_planes=4), "mixed128x4": lambda: edge_image(128, 128, "mixed", 4),
               "twocolor128": lambda: edge_image(128, 128, "twocolor", 3), "noise64": lambda: edge_image(64, 64, "noise", 3)}[case]()
-    e = HipTileEncoder(0)
+    e = HipTileEncoder(0, hooks=True)                        # the test build of the same kernel source: the switch exists only there
     try:
-        lib().yk_set_kernel_version(e._h, 2)
-        lib().yk_set_ablation(e._h, 16)
+        test_lib().yk_set_ablation(e._h, 16)
         for m3 in (False, True):
             bad = compare_encode(planes, e, m3)
             assert not bad, bad

@@ -67,11 +67,8 @@ def _image(seed, size, n_planes):
 
 @pytest.fixture(scope="module", params=[2, 1], ids=["kernel_v2", "kernel_v1"])
 def hip(request):
-    from yaik_amd._lib import lib
-    from yaik_amd.encoder import HipTileEncoder
-    e = HipTileEncoder(0)
-    from tests.parity import select_kernel_version
-    select_kernel_version(e, request.param)
+    from tests.parity import encoder_for_kernel_version
+    e = encoder_for_kernel_version(request.param)
     yield e
     e.close()
 

@@ -12,27 +12,27 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hip():
     from yaik_amd.encoder import HipTileEncoder
-    e = HipTileEncoder(0)
+    e = HipTileEncoder(0, hooks=True)                        # yk_selftest lives in the test build (include/yaik_hip_test.h), same kernel sources
     yield e
     e.close()
 
 
 def test_reciprocal_division_is_ieee_exact(hip):
-    from yaik_amd._lib import lib
+    from yaik_amd._lib import test_lib as lib
     res = C.c_int(-1)
     assert lib().yk_selftest(hip._h, 0, C.byref(res)) == 0
     assert res.value == 0, f"{res.value} of 65536 (minDiff, value) pairs differ from __fdiv_rn"
 
 
 def test_reciprocal_scale_division_is_exact(hip):
-    from yaik_amd._lib import lib
+    from yaik_amd._lib import test_lib as lib
     res = C.c_int(-1)
     assert lib().yk_selftest(hip._h, 1, C.byref(res)) == 0
     assert res.value == 0, f"{res.value} (scale, diff) pairs differ from the integer division of DiffRangeEncode"
 
 
 def test_reciprocal_model1_division_is_exact(hip):
-    from yaik_amd._lib import lib
+    from yaik_amd._lib import test_lib as lib
     res = C.c_int(-1)
     assert lib().yk_selftest(hip._h, 2, C.byref(res)) == 0
     assert res.value == 0, f"{res.value} (n, delta) pairs differ from the integer division of GetValueModel1"
@@ -42,7 +42,7 @@ def test_quantiser_table_matches_lut_scan(hip):
     """yk_encode2_kernel reads index / minDiff of a pixel from a table indexed by (rangeDecode, v - BN): for every (min, max) of a
     tile the LUTs built the reference's way must equal BN + K[rangeDecode], and every value in [min, max] must find in the table
     what the first-minimum scan of those LUTs finds."""
-    from yaik_amd._lib import lib
+    from yaik_amd._lib import test_lib as lib
     res = C.c_int(-1)
     assert lib().yk_selftest(hip._h, 3, C.byref(res)) == 0
     assert res.value == 0, f"{res.value} table entries differ from the LUT scan"

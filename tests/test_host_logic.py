@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == declared, (set(declared) ^ set(_lib.SIGNATURES))
 
 
+def test_product_library_carries_no_test_hooks():
+    """The hooks of include/yaik_hip_test.h (self-tests, ablations, cross-check registration) exist only in the test build."""
+    from yaik_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "yaik_hip_test.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(yk_[a-z0-9_]+)\s*\(", hdr)))
+    assert hooks == sorted(_lib.TEST_SIGNATURES) and len(hooks) == 4
+    product = C.CDLL(_lib.LIB_PATH)
+    assert not [s for s in hooks if hasattr(product, s)]
+    test = C.CDLL(_lib.TEST_LIB_PATH)
+    assert not [s for s in hooks + _declared_symbols() if not hasattr(test, s)]
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: without a HIP device the handle cannot even be created."""
     import torch

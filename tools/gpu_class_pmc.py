@@ -23,8 +23,10 @@ elif cls == "noise":
 if cls == "frame":
     from yaik_amd.synth import synth_planes_torch
     img = synth_planes_torch(W, W, 4, device=dev)
-enc = HipTileEncoder(0)
-lib().yk_set_ablation(enc._h, abl)
+enc = HipTileEncoder(0, hooks=abl != 0)              # ablation switches live in the test build of the library
+if abl:
+    from yaik_amd._lib import test_lib
+    test_lib().yk_set_ablation(enc._h, abl)
 enc.set_image(img.to(torch.int32).contiguous())
 if cls == 'frame':
     enc.alpha_reject(); enc.alpha_finish(None)

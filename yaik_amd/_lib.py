@@ -116,14 +116,36 @@ SIGNATURES = {
     "yk_decode_split_masks": (C.c_int, [vp]),
     "yk_decode_assign_lut": (C.c_int, [vp, vp, sz]),
     "yk_decode_lut3d": (C.c_int, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+    "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+# include/yaik_hip_test.h: only in the -DYK_TEST_HOOKS build (tests/csrc/libyaik_hip_test.so), never in the product library
+TEST_SIGNATURES = {
     "yk_selftest": (C.c_int, [vp, C.c_int, ip]),
     "yk_set_ablation": (C.c_int, [vp, C.c_int]),
     "yk_set_kernel_version": (C.c_int, [vp, C.c_int]),
     "yk_set_cross_check_launcher": (C.c_int, [vp]),
-    "yk_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
+TEST_LIB_PATH = os.environ.get("YK_TEST_LIB") or os.path.join(os.path.dirname(HERE), "tests", "csrc", "libyaik_hip_test.so")
 
 _lib = None
+_test_lib = None
+
+
+def test_lib() -> C.CDLL:
+    """The test build of the library (same sources + the hooks of include/yaik_hip_test.h).  Test infrastructure: only tests/ and tools/ load it."""
+    global _test_lib
+    if _test_lib is None:
+        lib()                                                # the product library first (and torch's HIP runtime before both)
+        if not os.path.exists(TEST_LIB_PATH):
+            raise YaikError(f"{TEST_LIB_PATH} is missing: make -C yaik_amd/csrc")
+        L = C.CDLL(TEST_LIB_PATH)
+        for name, (res, args) in {**SIGNATURES, **TEST_SIGNATURES}.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _test_lib = L
+    return _test_lib
 
 
 def lib() -> C.CDLL:

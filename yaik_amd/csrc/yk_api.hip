@@ -1,6 +1,9 @@
 // yk_api.hip — the C-ABI of include/yaik_hip.h: handle lifetime, HBM buffers, launch order, result getters.
 // Host-side glue only; every pixel is touched by the kernels in yk_stages.hip / yk_encode2.hip / yk_corners.hip / yk_partial.hip / yk_range1d.hip / yk_decode.hip.
 #include "yk_common.h"
+#ifdef YK_TEST_HOOKS
+#include "../../include/yaik_hip_test.h"
+#endif
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -382,12 +385,14 @@ int yk_alpha_bitmap(yk_ctx* c, uint8_t* hostOut, size_t cap, size_t* nBytes) {
 }
 
 // ---- fused encode ------------------------------------------------------------------------------------
+#ifdef YK_TEST_HOOKS                                     // include/yaik_hip_test.h: only in the test build of the library
 int yk_set_kernel_version(yk_ctx* c, int version) {
     if (!c || (version != 1 && version != 2)) return YK_ERR_BAD_ARG;
     c->kernelVersion = version; return YK_OK;
 }
 
 int yk_set_ablation(yk_ctx* c, int flags) { if (!c) return YK_ERR_BAD_ARG; c->ablate = flags; return YK_OK; }
+#endif
 
 int yk_set_dst_fill(yk_ctx* c, int32_t fill) { if (!c) return YK_ERR_BAD_ARG; c->dstFill = fill; return YK_OK; }
 

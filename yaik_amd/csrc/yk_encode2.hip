@@ -26,6 +26,12 @@
 __constant__ float c_curve2[6][16] = YK_CURVE_TABLE;
 
 #define LS YK_LSTRIDE
+// timing ablations / the forced exact path (yk_set_ablation, include/yaik_hip_test.h) exist in the test build only
+#ifdef YK_TEST_HOOKS
+#define YK2_ABLATE(bit) ((P.ablate & (bit)) != 0)
+#else
+#define YK2_ABLATE(bit) false
+#endif
 
 __device__ __forceinline__ int y2_byte(uint32_t w, int ch) { return (w >> (8 * ch)) & 255; }
 // |a - b| through the SAD unit (with a literal 0 addend the compiler would expand __usad into min/max/sub)
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         const unsigned long long deadLanes = __ballot(dead);
         YK2_STAT(75, 1); YK2_STAT(76, ~deadLanes == 0ULL ? 1 : 0); YK2_STAT(77, __popcll(deadLanes));
         const bool stripInside = (BX * 64 + 64 <= w) && (BY * 64 + wave * 16 + 16 <= h);     // no tile of the strip crosses the image's edge
-        if (~deadLanes != 0ULL && !(P.ablate & 2)) {
+        if (~deadLanes != 0ULL && !YK2_ABLATE(2)) {
             // corner lattice (every 4th pixel, 17 x 5 points incl. the halo): Round6 / Round6P of the three channels at once (SWAR)
             // and the five packed streams of y2_grad_pass
             auto latticePoint = [&](const int idx) {
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     // order = LeftRightOrder).  The counts are the same for the three planes.  A strip holds two runs of 8 consecutive tiles;
     // when the tile grid is a multiple of 8 wide a run never straddles a scan block and one lane adds the run's sums.
     {
-        const int n16 = (tileLive && !(P.ablate & 1)) ? (nTop + nBot) : 0;   // nibbles / 16 of this tile-plane
+        const int n16 = (tileLive && !YK2_ABLATE(1)) ? (nTop + nBot) : 0;   // nibbles / 16 of this tile-plane
         if (__ballot(writer && n16 > 0) != 0ULL) {
             if ((P.tilesW & 7) == 0) {
 #pragma unroll
@@ -805,7 +811,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     }
 
     YK2_STAT(70, validMask != 0ULL ? 1 : 0); YK2_STAT(74, __popcll(validMask));
-    if (validMask == 0ULL || (P.ablate & 1)) {
+    if (validMask == 0ULL || YK2_ABLATE(1)) {
         if (writer) {
 #pragma unroll
             for (int p = 0; p < 3; p++) tileCountP[p * T8 + tileIdx] = 0;
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         // ---- nearest LUT entry per pixel and mode: ONE 16-byte row of the quantiser table per pixel and plane, all sixteen of a plane in flight at once
         uint4 win[16];
         auto issueRows = [&](const int pl, const int k0, const int k1) {
-            if (valid && !(P.ablate & 4)) {
+            if (valid && !YK2_ABLATE(4)) {
                 const uint32_t q16 = (tdef[pl] & 0xFFFFu) << 4;
 #pragma unroll
                 for (int k = k0; k < k1; k++) {
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const uint32_t qrow16 = (tdef[p] & 0xFFFFu) << 4;               // byte offset of the row of v = 0 behind qrows
             float sm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             issueRows(p, YK2_PREF, 16);                                       // the rows that were not sent ahead
-            if (valid && !(P.ablate & 4)) {
+            if (valid && !YK2_ABLATE(4)) {
                 // The plane's sixteen rows are in flight already (issued before the previous plane's mode selection, see below); the index
                 // words wait in LDS (word = pixel * 64 + lane: conflict-free) until the mode is chosen.
                 float rvw[YK2_RVWIN];
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     if (k < 8) cLo = __builtin_amdgcn_alignbit(code, cLo, 4); else cHi = __builtin_amdgcn_alignbit(code, cHi, 4);
                 }
             }
-            if (P.ablate & 16) amb = true;                                   // test hook: force the exact re-summation everywhere
+            if (YK2_ABLATE(16)) amb = true;                                   // test hook: force the exact re-summation everywhere
             unsigned long long ambMask = __ballot(amb && tileLive);
             YK2_STAT(72, __popcll(ambMask) / 4); YK2_STAT(71, ambMask != 0ULL ? 1 : 0);
 #ifdef YK2_TIMING

@@ -8,6 +8,9 @@
 //
 // No MFMA: integer / byte work bounded by HBM streaming.
 #include "yk_common.h"
+#ifdef YK_TEST_HOOKS
+#include "../../include/yaik_hip_test.h"
+#endif
 #include "yk_device.h"
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -182,7 +185,9 @@ __global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // test hook: the launcher of an independent second implementation of the fused kernel (same YkEncodeParams, same outputs)
 static int (*g_crossCheckLauncher)(hipStream_t, const YkEncodeParams*) = nullptr;
+#ifdef YK_TEST_HOOKS
 extern "C" int yk_set_cross_check_launcher(void* fn) { g_crossCheckLauncher = reinterpret_cast<int (*)(hipStream_t, const YkEncodeParams*)>(fn); return YK_OK; }
+#endif
 
 int yk_launch_alpha(yk_ctx* c, bool batch) {
     const int F = batch ? c->nFrames : 1;
@@ -279,6 +284,7 @@ __global__ void yk_selftest_r1div_kernel(int* mismatches) {
     }
 }
 
+#ifdef YK_TEST_HOOKS
 extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     if (!c || !result) return YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));
@@ -295,3 +301,4 @@ extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     (void)hipFree(d);
     return YK_OK;
 }
+#endif
