@@ -81,11 +81,13 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
     def fence():
         torch.cuda.synchronize()
         enc.synchronize()
+        if dec is not None:
+            dec.synchronize()
         if world > 1:
             dist.barrier()
 
-    ST = {"corners": (0,), "range1d": (1, 2), "decode": (3, 4, 5), "lut3d": (6,)}[args.stage]
     dec = None
+    ST = {"corners": (0,), "range1d": (1, 2), "decode": (3, 4, 5), "lut3d": (6,)}[args.stage]
     if args.stage == "corners":
         step = enc.gradient_corners_run
     elif args.stage == "range1d":
@@ -115,13 +117,22 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         out = np.zeros((W, W * 3), dtype=np.uint8)
         shapes = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]
 
-        def step():
-            dec.begin(W, W)
-            for i, (sx, sy) in enumerate(shapes):
-                if counts[i]:
-                    dec.decompress_gradient(sx, sy, bitmaps[i], corners[i])
-            dec.decompress_1d(typ, pix)
-            dec.image_into(out)
+        if args.device_streams:
+            # the encoder's outputs feed the decoder where they lie in HBM (BASELINE config 5: encode + decode round trip on the GPU): no host
+            # streams, no PCIe; a step = all gradient passes + the 1-D chunk, the image stays in HBM as 8x8-tiled planes
+            dev_calls = dec.encoder_streams(enc)
+
+            def step():
+                dec.begin(W, W)
+                dec.decode_streams(dev_calls, sync=False)
+        else:
+            def step():
+                dec.begin(W, W)
+                for i, (sx, sy) in enumerate(shapes):
+                    if counts[i]:
+                        dec.decompress_gradient(sx, sy, bitmaps[i], corners[i])
+                dec.decompress_1d(typ, pix)
+                dec.image_into(out)
 
     def lib_call(e):
         from yaik_amd._lib import lib
@@ -569,6 +580,8 @@ def main() -> int:
                     "(f4) on a synthetic bank, after an encode")
     ap.add_argument("--layout", choices=["frames", "stripes"], default="frames", help="N > 1: frames = every rank encodes its own frames (weak scaling, "
                     "default); stripes = ONE image of --size, rank r owns a band of 64-row blocks + 1 halo row (strong scaling)")
+    ap.add_argument("--device-streams", action="store_true", help="--stage decode: feed the decoder the encoder's streams where they lie in HBM "
+                    "(yk_decode_gradient_device / yk_decode_1d_device) instead of host streams over PCIe")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size bit-exactness check against the oracle")
     ap.add_argument("--cpu-size", type=int, default=0, help="side of the centred crop timed on the CPU (default: whole frame)")

@@ -137,6 +137,8 @@ int    yk_coverage(yk_ctx* c, uint16_t* hostOut, size_t capElems);
 /* corner-colour stream of pass p = `rgbStream` (:4113-4132): CompressF(Round6(corner),250) bytes of every corner
  * not yet in `mappedRGB`, in scan order, de-duplicated across passes.  Call for p = 0..6 in order. */
 int    yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t cap, size_t* nBytes);
+/* pass's corner stream where it lies in HBM (valid until the handle's next encode) and its length; builds the streams on first use */
+int yk_gradient_corners_device(yk_ctx* c, int pass, const uint8_t** dev, size_t* nBytes);
 /* (re)builds the seven corner streams on the device without copying anything out (yk_gradient_corners does it on first use) */
 int    yk_gradient_corners_run(yk_ctx* c);
 /* Row stripes (new; SURVEY §8e "corner dedup across stripe-boundary lattice rows ... on the root"): a stripe handle
@@ -205,6 +207,8 @@ int yk_set_dst_fill(yk_ctx* c, int32_t fill);
  * per-tile parameter bytes color0,minCol,delta (`streamType`, :8503-8505).  colorCompression1D = 255, rangeCompression1D = 15. */
 int yk_range1d_encode(yk_ctx* c);
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType);
+/* the two streams where they lie in HBM (valid until the handle's next yk_range1d_encode / yk_set_image) and their lengths; synchronises once for the lengths */
+int yk_range1d_streams_device(yk_ctx* c, const uint8_t** devPix, size_t* nPix, const uint8_t** devType, size_t* nType);
 /* where plane p's share of the two streams ends (bytes, cumulative): the cursor DynamicTileCompressor returns after plane p (:8521) and
  * the end of its streamType entries.  Equal thirds unless a partial-plane pass gave the planes different coverage. */
 int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]);
@@ -268,6 +272,11 @@ int yk_decode_begin(yk_ctx* c, int w, int h);
  * bitmap = swizzled tile bitmap, rgb = corner stream AFTER PaletteDecompressor (0..255). Host pointers. */
 int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* bitmap, size_t bitmapBytes,
                        const uint8_t* rgb, size_t rgbBytes);
+/* The same with both streams already in HBM on the handle's device (e.g. straight from an encoder handle: yk_gradient_bitmap_device,
+ * yk_gradient_corners_device) and no host synchronisation.  remapRange > 0 applies PaletteFullRangeRemapping(range) to the colour stream on
+ * the way in (decoder/YAIK_GenericFunctions.cpp:128-137; the encoder's streams are CompressF(.., 250) values), 0 takes it as it is. */
+int yk_decode_gradient_device(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* devBitmap, size_t bitmapBytes,
+                              const uint8_t* devRgb, size_t rgbBytes, int remapRange);
 /* DecompressGradient4x4 with a plane subset (decoder/YAIK_Gradient.cpp:1208-1226 -> 4x4R / G / RG / B / RB / GB, :1420-2732): planeBit
  * 1..6 (bit 0 = R, 1 = G, 2 = B; 7 forwards to yk_decode_gradient).  Like YAIK_API.cpp:875-877 the masks are split per plane first
  * (UpdateTileAndRGBMask).  Only the 4x4 size has partial-plane loops in the reference.  consistentMarks = 0 reproduces what those loops
@@ -293,6 +302,8 @@ int yk_decode_lut3d(yk_ctx* c, const uint8_t* const maps[6], const size_t mapByt
 /* Decompress1D x3 planes (decoder/YAIK_3DTile.cpp:24-240) on the '1DTL' streams (type: 3 B/tile, pix: 1 B/pixel) */
 int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes,
                  int compressionRange);
+/* streams already in HBM (yk_range1d_streams_device of an encoder handle on the same device), no host synchronisation */
+int yk_decode_1d_device(yk_ctx* c, const uint8_t* devType, size_t typeBytes, const uint8_t* devPix, size_t pixBytes, int compressionRange);
 /* Decompress1BitTiled (decoder/YAIK_Mipmap.cpp:23-154): 1 bit / 16x16 tile -> swizzled 1 bit / pixel mask */
 int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int tileBBoxW, int tileBBoxH, uint8_t* hostOut, size_t cap);
 /* 8x8-tiled u8 planes exactly as YAIK_SCustomDataSource hands them to imageBuilderFunc (include/YAIK.h:205-224) */

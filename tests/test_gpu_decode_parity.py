@@ -153,3 +153,33 @@ def test_mask_decode(dec, oracle_built):
         src = ((bits[np.arange(bw * bh) >> 3] >> (np.arange(bw * bh) & 7)) & 1).reshape(bh, bw).astype(bool)
         assert np.array_equal(words[:, 0, :, 0] == np.uint64(0xFFFFFFFFFFFFFFFF), src)
         assert np.array_equal(words[:, 1, :, 1] == np.uint64(0xFFFFFFFFFFFFFFFF), src)
+
+
+@pytest.mark.parametrize("size,npl", [(256, 3), (512, 4), (1024, 4)])
+def test_decode_from_device_streams_equals_decode_from_host_streams(size, npl):
+    """yk_decode_gradient_device / yk_decode_1d_device (streams read where the encoder left them in HBM, corner streams remapped on the way
+    in) against the host-stream entry points the YAIK.h boundary uses: planes and tile4x4Mask identical."""
+    from oracle.pyoracle import PASSES, palette_remap
+    from yaik_amd.decoder import HipTileDecoder
+    from yaik_amd.encoder import HipTileEncoder
+    planes = synth_planes(size, n_planes=npl)
+    enc = HipTileEncoder(0)
+    a, b = HipTileDecoder(0), HipTileDecoder(0)
+    try:
+        enc.set_image(planes)
+        if npl == 4:
+            enc.mip_prefilter()
+        enc.encode(3, False, False)
+        counts = enc.gradient_counts()
+        a.begin(size, size)
+        for i, (sx, sy) in enumerate(PASSES):
+            if counts[i]:
+                a.decompress_gradient(sx, sy, enc.gradient_bitmap(i), palette_remap(enc.gradient_corners(i), 250))
+        pix, typ = enc.dynamic_tile_compressor()
+        a.decompress_1d(typ, pix)
+        b.begin(size, size)
+        b.decode_from_encoder(enc)
+        assert np.array_equal(a.planes(), b.planes())
+        assert np.array_equal(a.tile4x4(), b.tile4x4())
+    finally:
+        a.close(); b.close(); enc.close()

@@ -293,6 +293,16 @@ extern "C" int yk_gradient_corners(yk_ctx* c, int pass, uint8_t* hostOut, size_t
     return YK_OK;
 }
 
+extern "C" int yk_gradient_corners_device(yk_ctx* c, int pass, const uint8_t** dev, size_t* nBytes) {
+    if (!c || pass < 0 || pass >= 7 || !dev || !nBytes) return YK_ERR_BAD_ARG;
+    if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");
+    YK_HIP(c, hipSetDevice(c->device));
+    if (!c->cornersReady) { int rc = yk_launch_corners(c); if (rc) return rc; }
+    { int rc = yk_corners_finish(c); if (rc) return rc; }
+    *dev = c->cornerStream + c->cornerOff[pass]; *nBytes = c->cornerBytes[pass];
+    return YK_OK;
+}
+
 extern "C" int yk_gradient_corners_run(yk_ctx* c) {
     if (!c) return YK_ERR_BAD_ARG;
     if (!c->encoded) return yk_fail(c, YK_ERR_STATE, "yk_encode_tiles first");

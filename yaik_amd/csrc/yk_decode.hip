@@ -419,20 +419,22 @@ int yk_decode_begin(yk_ctx* c, int w, int h) {
     if (!c) return YK_ERR_BAD_ARG;
     if (w < 16 || h < 16 || (w & 15) || (h & 15) || w > 32752 || h > 32752) return yk_fail(c, YK_ERR_BAD_ARG, "decode needs width/height multiples of 16");
     YK_HIP(c, hipSetDevice(c->device));
-    YK_HIP(c, hipStreamSynchronize(c->stream));
-    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dLoaded);
-    c->dw = w; c->dh = h;
-    const int tileW = w >> 3, tileH = h >> 3;
-    c->dPlaneSize = (size_t)tileW * tileH * 64;
     const size_t lat = (size_t)(w / 4 + 1) * (h / 4 + 1);
-    const int stride4 = (w + 15) >> 4;
-    c->dTile4Size = (size_t)((stride4 << 2) * (((h + 7) >> 3) << 1)) >> 3;
-    YK_HIP(c, hipMalloc(&c->dPlanes, c->dPlaneSize * 3));
-    YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3));
-    YK_HIP(c, hipMalloc(&c->dLatticeOwner, lat * 4));
-    YK_HIP(c, hipMalloc(&c->dLoaded, lat));
-    YK_HIP(c, hipMalloc(&c->dTile4, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4));       // three planes once the masks are split
+    if (!c->dPlanes || c->dw != w || c->dh != h) {                             // a stream of images of one shape keeps its buffers: only the clears below
+        YK_HIP(c, hipStreamSynchronize(c->stream));
+        auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+        F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dLoaded);
+        c->dw = w; c->dh = h;
+        const int tileW = w >> 3, tileH = h >> 3;
+        c->dPlaneSize = (size_t)tileW * tileH * 64;
+        const int stride4 = (w + 15) >> 4;
+        c->dTile4Size = (size_t)((stride4 << 2) * (((h + 7) >> 3) << 1)) >> 3;
+        YK_HIP(c, hipMalloc(&c->dPlanes, c->dPlaneSize * 3));
+        YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3));
+        YK_HIP(c, hipMalloc(&c->dLatticeOwner, lat * 4));
+        YK_HIP(c, hipMalloc(&c->dLoaded, lat));
+        YK_HIP(c, hipMalloc(&c->dTile4, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4));   // three planes once the masks are split
+    }
     YK_HIP(c, hipMemsetAsync(c->dPlanes, 0, c->dPlaneSize * 3, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dMapRGB, 0, lat * 3, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dLoaded, 0, lat, c->stream));
@@ -441,7 +443,12 @@ int yk_decode_begin(yk_ctx* c, int w, int h) {
     return YK_OK;
 }
 
-int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes) {
+// PaletteFullRangeRemapping (decoder/YAIK_GenericFunctions.cpp:128-137) of a corner stream that is still in HBM: v * ((255 << 16) / range) >> 16
+__global__ void yk_dec_remap_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n, uint32_t factor) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint8_t)(((uint32_t)src[i] * factor) >> 16);
+}
+
+static int yk_decode_gradient_impl(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes, bool onDevice, int remapRange) {
     if (!c || !bitmap) return YK_ERR_BAD_ARG;
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
     static const int ok[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
@@ -459,8 +466,13 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
     int rc = yk_dec_scratch(c, oT + 64); if (rc) return rc;
     uint8_t* S = c->dScratch;
     YK_HIP(c, hipMemsetAsync(S + oB, 0, nWords * 4, c->stream));
-    YK_HIP(c, hipMemcpyAsync(S + oB, bitmap, need, hipMemcpyHostToDevice, c->stream));
-    if (rgbBytes) YK_HIP(c, hipMemcpyAsync(S + oR, rgb, rgbBytes, hipMemcpyHostToDevice, c->stream));
+    YK_HIP(c, hipMemcpyAsync(S + oB, bitmap, need, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (rgbBytes) {
+        if (onDevice && remapRange > 0)
+            hipLaunchKernelGGL(yk_dec_remap_kernel, dim3((unsigned)((rgbBytes + 255) / 256 < 1024 ? (rgbBytes + 255) / 256 : 1024)), dim3(256), 0, c->stream,
+                               rgb, S + oR, rgbBytes, (uint32_t)((255u << 16) / (uint32_t)remapRange));
+        else YK_HIP(c, hipMemcpyAsync(S + oR, rgb, rgbBytes, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    }
     YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
     const uint32_t* bm = reinterpret_cast<const uint32_t*>(S + oB);
     uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oBB);
@@ -476,8 +488,16 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
                        w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
     YK_HIP(c, hipGetLastError());
     { int rc2 = yk_stage_end(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
-    YK_HIP(c, hipStreamSynchronize(c->stream));            // the host buffers may be reused by the caller
+    if (!onDevice) YK_HIP(c, hipStreamSynchronize(c->stream));            // the host buffers may be reused by the caller
     return YK_OK;
+}
+
+int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t bitmapBytes, const uint8_t* rgb, size_t rgbBytes) {
+    return yk_decode_gradient_impl(c, sx, sy, bitmap, bitmapBytes, rgb, rgbBytes, false, 0);
+}
+
+int yk_decode_gradient_device(yk_ctx* c, int sx, int sy, const uint8_t* devBitmap, size_t bitmapBytes, const uint8_t* devRgb, size_t rgbBytes, int remapRange) {
+    return yk_decode_gradient_impl(c, sx, sy, devBitmap, bitmapBytes, devRgb, rgbBytes, true, remapRange);
 }
 
 static int yk_dec_split(yk_ctx* c) {                                       // UpdateTileAndRGBMask (YAIK_API.cpp:530-544), once
@@ -535,7 +555,7 @@ int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, cons
 
 __global__ void yk_dec1d_next_plane_kernel(uint32_t* __restrict__ runBase, const uint32_t* __restrict__ tot) { if (threadIdx.x < 2) runBase[threadIdx.x] += tot[threadIdx.x]; }
 
-int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes, int compressionRange) {
+static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes, int compressionRange, bool onDevice) {
     if (!c || !typeStream || !pixStream || compressionRange <= 0) return YK_ERR_BAD_ARG;
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
     YK_HIP(c, hipSetDevice(c->device));
@@ -545,8 +565,13 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
                  oBT = oCP + 16, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16;
     int rc = yk_dec_scratch(c, oTot + 64); if (rc) return rc;
     uint8_t* S = c->dScratch;
-    YK_HIP(c, hipMemcpyAsync(S + oTy, typeStream, typeBytes, hipMemcpyHostToDevice, c->stream));
-    YK_HIP(c, hipMemcpyAsync(S + oPx, pixStream, pixBytes, hipMemcpyHostToDevice, c->stream));
+    // streams that already lie in HBM (16-byte aligned, as the encoder leaves them) are read where they are
+    const bool inPlace = onDevice && ((reinterpret_cast<uintptr_t>(typeStream) | reinterpret_cast<uintptr_t>(pixStream)) & 15) == 0;
+    if (!inPlace) {
+        YK_HIP(c, hipMemcpyAsync(S + oTy, typeStream, typeBytes, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        YK_HIP(c, hipMemcpyAsync(S + oPx, pixStream, pixBytes, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    }
+    const uint8_t* const tyS = inPlace ? typeStream : S + oTy; const uint8_t* const pxS = inPlace ? pixStream : S + oPx;
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
@@ -555,7 +580,7 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
         hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP);
         hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
         hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
-                           S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, -1, (const uint32_t*)nullptr);
+                           tyS, typeBytes, pxS, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, -1, (const uint32_t*)nullptr);
     } else {
         // per-plane masks (Decompress1D reads tile4x4Mask + planeID * tile4x4MaskSize, YAIK_3DTile.cpp:41): one plane after the other,
         // every plane's streams start where the plane before it stopped
@@ -566,14 +591,22 @@ int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const u
             hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP);
             hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
             hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
-                               S + oTy, typeBytes, S + oPx, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, p, (const uint32_t*)runBase);
+                               tyS, typeBytes, pxS, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, p, (const uint32_t*)runBase);
             hipLaunchKernelGGL(yk_dec1d_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
         }
     }
     YK_HIP(c, hipGetLastError());
     { int rc2 = yk_stage_end(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
-    YK_HIP(c, hipStreamSynchronize(c->stream));
+    if (!onDevice) YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
+}
+
+int yk_decode_1d(yk_ctx* c, const uint8_t* typeStream, size_t typeBytes, const uint8_t* pixStream, size_t pixBytes, int compressionRange) {
+    return yk_decode_1d_impl(c, typeStream, typeBytes, pixStream, pixBytes, compressionRange, false);
+}
+
+int yk_decode_1d_device(yk_ctx* c, const uint8_t* devType, size_t typeBytes, const uint8_t* devPix, size_t pixBytes, int compressionRange) {
+    return yk_decode_1d_impl(c, devType, typeBytes, devPix, pixBytes, compressionRange, true);
 }
 
 int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int bw, int bh, uint8_t* hostOut, size_t cap) {

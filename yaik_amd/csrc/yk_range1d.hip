@@ -263,6 +263,14 @@ int yk_range1d_plane_ends(yk_ctx* c, size_t pixEnd[3], size_t typeEnd[3]) {
     return YK_OK;
 }
 
+int yk_range1d_streams_device(yk_ctx* c, const uint8_t** devPix, size_t* nPix, const uint8_t** devType, size_t* nType) {
+    if (!c || !devPix || !nPix || !devType || !nType) return YK_ERR_BAD_ARG;
+    if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");
+    { int rc = yk_range1d_finish(c); if (rc) return rc; }
+    *devPix = c->r1Pix; *nPix = (size_t)c->r1PixCount; *devType = c->r1Type; *nType = (size_t)c->r1Tiles * 3;
+    return YK_OK;
+}
+
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType) {
     if (!c) return YK_ERR_BAD_ARG;
     if (!c->r1Ready) return yk_fail(c, YK_ERR_STATE, "yk_range1d_encode first");

@@ -40,6 +40,40 @@ class HipTileDecoder:
         _chk(self._h, lib().yk_decode_gradient(self._h, sx, sy, bitmap.ctypes.data, bitmap.size,
                                                rgb_dq.ctypes.data if rgb_dq.size else None, rgb_dq.size))
 
+    def encoder_streams(self, enc) -> list:
+        """The device-resident streams of an encoder handle on the same device, as the argument lists of yk_decode_gradient_device (one per
+        gradient pass with accepted tiles) and yk_decode_1d_device: tile bitmaps, corner streams and the 1-D streams where the encoder left
+        them in HBM.  Runs the encoder's corner and 1-D stages if they have not run, and fences the encoder once (for the lengths)."""
+        shapes = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]
+        counts = enc.gradient_counts()
+        calls = []
+        for i, (sx, sy) in enumerate(shapes):
+            dev, n = C.c_void_p(), C.c_size_t()
+            _chk(enc._h, enc._L.yk_gradient_corners_device(enc._h, i, C.byref(dev), C.byref(n)))
+            if counts[i]:
+                calls.append(("g", sx, sy, enc._L.yk_gradient_bitmap_device(enc._h, i), enc._L.yk_gradient_bitmap_bytes(enc._h, i), dev, n.value))
+        _chk(enc._h, enc._L.yk_range1d_encode(enc._h))
+        pix, npx, typ, nty = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        _chk(enc._h, enc._L.yk_range1d_streams_device(enc._h, C.byref(pix), C.byref(npx), C.byref(typ), C.byref(nty)))
+        calls.append(("1", typ, nty.value, pix, npx.value))
+        enc.synchronize()
+        return calls
+
+    def decode_streams(self, calls: list, sync: bool = True) -> None:
+        """All gradient chunks + the 1-D chunk from device-resident streams (encoder_streams): the corner streams are remapped like
+        PaletteFullRangeRemapping(250) on the way in; no PCIe hop, no host synchronisation between the passes."""
+        L = lib()
+        for c in calls:
+            if c[0] == "g":
+                _chk(self._h, L.yk_decode_gradient_device(self._h, c[1], c[2], c[3], c[4], c[5], c[6], 250))
+            else:
+                _chk(self._h, L.yk_decode_1d_device(self._h, c[1], c[2], c[3], c[4], 15))
+        if sync:
+            _chk(self._h, L.yk_synchronize(self._h))
+
+    def decode_from_encoder(self, enc, sync: bool = True) -> None:
+        self.decode_streams(self.encoder_streams(enc), sync)
+
     def decompress_gradient_planes(self, plane_bit: int, bitmap: np.ndarray, rgb_dq: np.ndarray, consistent_marks: bool = False):
         """DecompressGradient4x4 with planeBit 1..6; consistent_marks=False leaves tile4x4Mask as the reference's loops do (defects included)."""
         bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
@@ -99,6 +133,9 @@ class HipTileDecoder:
     def image_into(self, out: np.ndarray) -> None:
         """RGB rows into a caller-owned [h, stride] uint8 array (no allocation per call)."""
         _chk(self._h, lib().yk_decode_output(self._h, out.ctypes.data, out.shape[1], None, 0))
+
+    def synchronize(self):
+        _chk(self._h, lib().yk_synchronize(self._h))
 
     def stage_ms(self, stage: int) -> tuple[float, int]:
         ms, n = C.c_float(), C.c_int()
