@@ -9,8 +9,8 @@ out = {}
 
 def short(name):
     name = name.split("(")[0].strip()
-    name = name.split(" ")[-1]
-    return name.split("<")[0]                      # template instantiations (yk_encode2_kernel<false>) under the kernel's name
+    name = name.split("<")[0].strip()              # template instantiations (yk_encode2_kernel<false, false>) under the kernel's name
+    return name.split(" ")[-1]
 
 for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
