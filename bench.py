@@ -174,7 +174,10 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         pixn = uncovered * 3
         alg = 2 * pixn + (W // 8) * (W // 8) * 9             # yk_dec1d_kernel: 1 B per uncovered pixel and plane read, the same written, 3 parameter bytes per tile-plane
         kname, kms, bound = "yk_dec1d_kernel (+ count / scan kernels)", per[4], "hbm"
-        note = (f"other decode kernels per frame: gradient owner/corner/render x{ms[3][1] // max(1, args.steps)} passes {per[3]:.4f} ms, "
+        gcalls = ms[3][1] // max(1, args.steps)
+        gform = ("all passes in ONE call (yk_decode_gradient_all_device: lattice clear + owner + count + scan + emit for all passes, then one render per pass = 11 launches)"
+                 if args.device_streams and gcalls == 1 else f"owner/corner/render x{gcalls} passes (5 launches + 3 copies / clears each)")
+        note = (f"other decode kernels per frame: gradient {gform} {per[3]:.4f} ms, "
                 f"yk_dec_detile_kernel {per[5]:.4f} ms (6 B/pixel moved = {6 * W * W / (per[5] * 1e-3) / 1e9 if per[5] > 0 else 0:.0f} GB/s)")
     achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     result = {
@@ -183,7 +186,7 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/int32", "data": "synthetic (YAIK-synth v1, seed 12345+rank)",
         "config": {"workload": f"{W}x{W} RGBA frame per GPU, stage '{args.stage}' of the tile path after a full encode; a step is one call sequence through the "
-                               "C-ABI incl. its host-side part (decode: host streams in, interleaved RGB image out over PCIe)",
+                               "C-ABI incl. its host-side part (decode: " + ("the encoder's streams read where they lie in HBM, 8x8-tiled planes left in HBM: no PCIe" if getattr(args, "device_streams", False) and args.stage == "decode" else "host streams in, interleaved RGB image out over PCIe") + ")",
                    "parallelism": f"replicas x{world} (no collective)" if world > 1 else "single GPU"},
         # `bound` names what limits the stage's dominant kernel; achieved / frac are its algorithmic bytes against the HBM figure either way
         # (for a latency- or VALU-bound kernel that fraction says how far from a byte-bound kernel it is, not how well it is tuned)

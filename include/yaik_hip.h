@@ -277,6 +277,12 @@ int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t*
  * the way in (decoder/YAIK_GenericFunctions.cpp:128-137; the encoder's streams are CompressF(.., 250) values), 0 takes it as it is. */
 int yk_decode_gradient_device(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* devBitmap, size_t bitmapBytes,
                               const uint8_t* devRgb, size_t rgbBytes, int remapRange);
+/* All 'GTIL' chunks of a file at once, streams in HBM: the same result as yk_decode_gradient_device for pass 0 .. nPasses-1 in that order
+ * (first toucher of every lattice point over ALL passes in one launch, one scan, one launch popping the colours, then one render per
+ * pass from a list of its non-empty bitmap words: 11 launches for seven passes instead of 35 + 21 copies / clears).  Up to seven passes per
+ * call and 2^25 tile slots per pass; beyond that the call runs the passes one after the other. */
+int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX, const int* tileShiftY, const uint8_t* const* devBitmap,
+                                  const size_t* bitmapBytes, const uint8_t* const* devRgb, const size_t* rgbBytes, int remapRange);
 /* DecompressGradient4x4 with a plane subset (decoder/YAIK_Gradient.cpp:1208-1226 -> 4x4R / G / RG / B / RB / GB, :1420-2732): planeBit
  * 1..6 (bit 0 = R, 1 = G, 2 = B; 7 forwards to yk_decode_gradient).  Like YAIK_API.cpp:875-877 the masks are split per plane first
  * (UpdateTileAndRGBMask).  Only the 4x4 size has partial-plane loops in the reference.  consistentMarks = 0 reproduces what those loops

@@ -178,8 +178,58 @@ def test_decode_from_device_streams_equals_decode_from_host_streams(size, npl):
         pix, typ = enc.dynamic_tile_compressor()
         a.decompress_1d(typ, pix)
         b.begin(size, size)
-        b.decode_from_encoder(enc)
+        b.decode_from_encoder(enc)                                   # the gradient chunks through ONE yk_decode_gradient_all_device call
+        assert np.array_equal(a.planes(), b.planes())
+        assert np.array_equal(a.tile4x4(), b.tile4x4())
+        b.begin(size, size)
+        b.decode_from_encoder(enc, per_pass=True)                    # one yk_decode_gradient_device call per chunk
         assert np.array_equal(a.planes(), b.planes())
         assert np.array_equal(a.tile4x4(), b.tile4x4())
     finally:
         a.close(); b.close(); enc.close()
+
+
+@pytest.mark.parametrize("seed,size,density", [(1, 256, 0.05), (2, 512, 0.3), (3, 384, 0.02), (4, 512, 0.6)])
+def test_all_pass_gradient_decode_on_arbitrary_streams(seed, size, density):
+    """yk_decode_gradient_all_device against the per-pass host entry point (pinned to the reference by the fixtures above) on streams no encoder
+    writes: random bitmaps per pass, so tiles of different passes overlap (the later pass must win, corners are popped once per lattice
+    point in pass and scan order), a colour stream that ends early (missing bytes read as 0) and a pass order that is not the file's."""
+    import ctypes as C
+    import torch
+    from oracle.pyoracle import PASSES, palette_remap
+    from yaik_amd._lib import lib
+    from yaik_amd.decoder import HipTileDecoder
+    from yaik_amd.encoder import _chk
+    rng = np.random.default_rng(seed)
+    order = list(range(7))
+    if seed & 1:
+        rng.shuffle(order)
+    w = h = size
+    bitmaps, rgbs = [], []
+    for i in order:
+        sx, sy = PASSES[i]
+        bigX, bigY = (32 if sx == 2 else 64), (32 if sy == 2 else 64)
+        nbits = ((w + bigX - 1) // bigX) * ((h + bigY - 1) // bigY) * (bigX >> sx) * (bigY >> sy)
+        bits = (rng.random(nbits) < density * (0.2 if i == 0 else 1.0)).astype(np.uint8)
+        bitmaps.append(np.packbits(bits, bitorder="little"))
+        n = int(bits.sum()) * 12
+        rgbs.append(rng.integers(0, 251, size=max(n - (7 if i == order[-1] else 0), 0), dtype=np.uint8))   # the last stream is short
+    a, b = HipTileDecoder(0), HipTileDecoder(0)
+    try:
+        a.begin(w, h)
+        for k, i in enumerate(order):
+            a.decompress_gradient(PASSES[i][0], PASSES[i][1], bitmaps[k], palette_remap(rgbs[k], 250))
+        b.begin(w, h)
+        dev_b = [torch.from_numpy(x.copy()).cuda() for x in bitmaps]
+        dev_r = [torch.from_numpy(np.concatenate([x, np.zeros(1, np.uint8)])).cuda() for x in rgbs]
+        n = 7
+        sx = (C.c_int * n)(*[PASSES[i][0] for i in order]); sy = (C.c_int * n)(*[PASSES[i][1] for i in order])
+        bm = (C.c_void_p * n)(*[t.data_ptr() for t in dev_b]); nb = (C.c_size_t * n)(*[x.size for x in bitmaps])
+        rp = (C.c_void_p * n)(*[t.data_ptr() for t in dev_r]); nr = (C.c_size_t * n)(*[x.size for x in rgbs])
+        torch.cuda.synchronize()
+        _chk(b._h, lib().yk_decode_gradient_all_device(b._h, n, sx, sy, bm, nb, rp, nr, 250))
+        b.synchronize()
+        assert np.array_equal(a.planes(), b.planes())
+        assert np.array_equal(a.tile4x4(), b.tile4x4())
+    finally:
+        a.close(); b.close()

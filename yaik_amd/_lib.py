@@ -105,6 +105,7 @@ SIGNATURES = {
     "yk_decode_1d": (C.c_int, [vp, vp, sz, vp, sz, C.c_int]),
     "yk_decode_1d_device": (C.c_int, [vp, vp, sz, vp, sz, C.c_int]),
     "yk_decode_gradient_device": (C.c_int, [vp, C.c_int, C.c_int, vp, sz, vp, sz, C.c_int]),
+    "yk_decode_gradient_all_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]),
     "yk_range1d_streams_device": (C.c_int, [vp, C.POINTER(vp), szp, C.POINTER(vp), szp]),
     "yk_gradient_corners_device": (C.c_int, [vp, C.c_int, C.POINTER(vp), szp]),
     "yk_decode_mask": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, sz]),

@@ -84,50 +84,46 @@ __global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __r
 // One workgroup per bitmap word.  The word's tiles are listed in LDS and the (tile, channel, row, run) items are spread over all 256
 // threads, so small tiles keep the workgroup as busy as large ones.  A thread produces a run of min(TX, 8) pixels of one row
 // and channel: in the 8x8-tiled plane layout that run is contiguous and leaves as ONE 8-byte (or 4-byte) store.
-__global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
-                                                            const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
-                                                            uint32_t* __restrict__ tile4, int stride4) {
-    __shared__ int s_xy[32][2];
-    const size_t wi = blockIdx.x;
-    const uint32_t bits = bitmap[wi];
-    if (!bits) return;
+struct DRenderLds { int xy[32][2]; uint8_t c[32][3][4]; };
+__device__ __forceinline__ void yk_dec_render_word(DRenderLds& L, const size_t wi, const uint32_t bits, const DPassGeo& g, int w, int h, int latW,
+                                                   const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                   uint32_t* __restrict__ tile4, int stride4) {
     const int TX = 1 << g.sx, TY = 1 << g.sy, dx = TX >> 2, dy = TY >> 2;
     const int lgGpr = g.sx > 3 ? g.sx - 3 : 0, lgPer = g.sy + lgGpr;            // runs per row, runs per channel (powers of two)
     const int GW = TX < 8 ? TX : 8, gpr = 1 << lgGpr, perCh = 1 << lgPer, nEl = 3 * perCh, sh = g.sx + g.sy;
     if (threadIdx.x < 32 && ((bits >> threadIdx.x) & 1u)) {
         int x, y; yk_dtile_from_bit(g, (uint32_t)(wi * 32 + threadIdx.x), x, y);
         const int k = __popc(bits & ((1u << threadIdx.x) - 1u));
-        s_xy[k][0] = (x + TX > w || y + TY > h) ? -1 : x; s_xy[k][1] = y;
+        L.xy[k][0] = (x + TX > w || y + TY > h) ? -1 : x; L.xy[k][1] = y;
     }
     __syncthreads();
     const int nT = __popc(bits);
     // the four corner colours of the word's tiles, once (every run of a tile used to fetch them again: 4 byte loads per 8-byte store)
-    __shared__ uint8_t s_c[32][3][4];
     for (int i = threadIdx.x; i < nT * 12; i += 256) {
         const int k = i / 12, e = i - 12 * k, c = e >> 2, q = e & 3;
-        const int x = s_xy[k][0], y = s_xy[k][1];
+        const int x = L.xy[k][0], y = L.xy[k][1];
         if (x < 0) continue;
         const size_t li = (size_t)((y >> 2) + ((q & 2) ? dy : 0)) * latW + (x >> 2) + ((q & 1) ? dx : 0);
-        s_c[k][c][q] = mapRGB[li * 3 + c];
+        L.c[k][c][q] = mapRGB[li * 3 + c];
     }
     __syncthreads();
     for (int item = threadIdx.x; item < nT * nEl; item += 256) {
         const int ck = item >> lgPer, k = ck / 3, c = ck - 3 * k;               // tile of the word, channel
-        const int x = s_xy[k][0], y = s_xy[k][1];
+        const int x = L.xy[k][0], y = L.xy[k][1];
         if (x < 0) continue;
         const int r = item & (perCh - 1), ty = r >> lgGpr, gx = (r & (gpr - 1)) * GW;
-        const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&s_c[k][c][0]);
+        const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&L.c[k][c][0]);
         const int TL = c4 & 255, TR = (c4 >> 8) & 255, BL = (c4 >> 16) & 255, BR = c4 >> 24;
-        const int L = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
-        int v = L * (TX - gx) + R * gx;                                         // numerator at the first pixel of the run, + (R - L) per pixel
+        const int Lf = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
+        int v = Lf * (TX - gx) + R * gx;                                        // numerator at the first pixel of the run, + (R - L) per pixel
         const int xx = x + gx, yy = y + ty;
         uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7);
         uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - L; }
+        for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
         if (GW == 8) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - L; }
+            for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
             *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
         } else *reinterpret_cast<uint32_t*>(o) = lo;
     }
@@ -136,7 +132,7 @@ __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __re
     // atomic per byte with all of the tile's bits in it (one per CELL was 16 device-scope atomics per 16x16 tile: most of this kernel)
     for (int item = threadIdx.x; item < nT * 2; item += 256) {
         const int k = item >> 1, j = item & 1;
-        const int x = s_xy[k][0], y = s_xy[k][1];
+        const int x = L.xy[k][0], y = L.xy[k][1];
         if (x < 0) continue;
         const int cx0 = x >> 2, cy0 = y >> 2, br = (cy0 >> 1) + j;                // byte row
         if (br > ((cy0 + dy - 1) >> 1)) continue;
@@ -145,6 +141,205 @@ __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __re
             for (int cx = cx0; cx < cx0 + dx; cx++) m |= 1u << ((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
         const size_t byteIdx = (size_t)(cx0 >> 2) + (size_t)br * stride4;
         atomicOr(&tile4[byteIdx >> 2], m << (8 * (byteIdx & 3)));
+    }
+}
+
+__global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
+                                                            const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                            uint32_t* __restrict__ tile4, int stride4) {
+    __shared__ DRenderLds L;
+    const size_t wi = blockIdx.x;
+    const uint32_t bits = bitmap[wi];
+    if (!bits) return;
+    yk_dec_render_word(L, wi, bits, g, w, h, latW, mapRGB, planes, planeSize, tileW, tile4, stride4);
+}
+
+// ---- all gradient chunks of a file in one call (yk_decode_gradient_all_device): the passes share every launch except the render --------------
+// What the per-pass sequence above does pass after pass (first toucher among the lattice points no EARLIER pass loaded, count, scan, pop the
+// colours) is one first-toucher problem over all passes when the key carries the pass: owner = min(pass << 27 | bitIndex << 2 | corner), the
+// layout of yk_corners.hip on the encoder side.  Bitmap bytes (8 tile slots) of all passes are laid end to end; 1024 bytes per workgroup.
+struct DecPlan {
+    uint32_t byteStart[8], blockStart[8], wordStart[8];     // first bitmap byte / 1024-byte block / list word of pass p ([n..7] = totals)
+    uint32_t nBytes[7], rgbBytes[7];
+    const uint8_t* bm[7];
+    const uint8_t* rgb[7];
+    int sx[7], sy[7];
+    int n;
+};
+__device__ __forceinline__ int yk_dplan_find(const uint32_t (&start)[8], uint32_t i) {
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < 7; k++) p += (i >= start[k]) ? 1 : 0;
+    return p;
+}
+// tiles of a bitmap byte: the 8 slots lie in one swizzle block (every block holds a multiple of 8 tiles); tiles per row / block are powers of two
+struct DByteGeo { int bx0, by0, tprShift, tprMask; uint32_t t0; };
+__device__ __forceinline__ DByteGeo yk_dbyte_geo(const DPassGeo& g, uint32_t bi) {
+    DByteGeo b;
+    const uint32_t pos0 = bi * 8u, blk = pos0 / (uint32_t)g.bitCount;
+    b.t0 = pos0 % (uint32_t)g.bitCount;
+    b.bx0 = (int)(blk % (uint32_t)g.xBB) * g.bigX; b.by0 = (int)(blk / (uint32_t)g.xBB) * g.bigY;
+    b.tprShift = __ffs(g.tilesPerRow) - 1; b.tprMask = g.tilesPerRow - 1;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void yk_decall_owner_kernel(const DecPlan pl, int w, int h, int latW, const uint8_t* __restrict__ loaded, uint32_t* __restrict__ owner) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= pl.byteStart[7]) return;
+    const int pass = yk_dplan_find(pl.byteStart, gi);
+    const uint32_t bi = gi - pl.byteStart[pass];
+    const uint32_t byte = pl.bm[pass][bi];
+    if (!byte) return;
+    const DPassGeo g = yk_dpass_geo(pl.sx[pass], pl.sy[pass], w);
+    const DByteGeo b = yk_dbyte_geo(g, bi);
+    const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (!((byte >> k) & 1u)) continue;
+        const uint32_t t = b.t0 + (uint32_t)k;
+        const int x = b.bx0 + (int)((t & (uint32_t)b.tprMask) << g.sx), y = b.by0 + (int)((t >> b.tprShift) << g.sy);
+        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;            // the reference skips tiles that leave the image (:58-60)
+        const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const size_t li = (size_t)((y >> 2) + ((q & 2) ? dy : 0)) * latW + (x >> 2) + ((q & 1) ? dx : 0);
+            if (!(loaded[li] & 1)) atomicMin(&owner[li], key | (uint32_t)q);
+        }
+    }
+}
+
+// COUNT: corners owned per thread (a byte, kept for the emit launch) and per workgroup, non-empty bitmap words per workgroup.
+// EMIT: the owners pop their colours off the pass's stream (offset = scanned corners before them x 3) into the lattice; the workgroup's
+// non-empty words are appended to the pass's render list.
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void yk_decall_stream_kernel(const DecPlan pl, int w, int h, int latW, uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner,
+                                                                uint32_t* __restrict__ blockSums, uint32_t* __restrict__ blockWords, uint8_t* __restrict__ perThread,
+                                                                uint8_t* __restrict__ mapRGB, uint32_t* __restrict__ wordList, uint32_t factor) {
+    __shared__ uint32_t s_tmp[32];
+    const int pass = yk_dplan_find(pl.blockStart, blockIdx.x);
+    const uint32_t bi = (blockIdx.x - pl.blockStart[pass]) * 1024u + threadIdx.x;
+    const uint32_t nBytes = pl.nBytes[pass];
+    const size_t ti = (size_t)pl.byteStart[pass] + bi;
+    const uint8_t* const bm = pl.bm[pass];
+    const uint32_t byte = bi < nBytes ? bm[bi] : 0u;
+    // a word of the bitmap is 4 consecutive bytes: its first thread speaks for it
+    bool wordSet = false;
+    if ((threadIdx.x & 3) == 0 && bi < nBytes) {
+        wordSet = byte != 0u;
+#pragma unroll
+        for (int j = 1; j < 4; j++) wordSet |= (bi + j < nBytes) && bm[bi + j] != 0;
+    }
+    const DPassGeo g = yk_dpass_geo(pl.sx[pass], pl.sy[pass], w);
+    const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+    uint32_t cnt = 0;
+    if (EMIT) cnt = bi < nBytes ? perThread[ti] : 0u;
+    uint32_t own[8];
+    int tx[8], ty[8];
+    if ((!EMIT && byte) || cnt) {
+        uint32_t o[8][4];
+        const DByteGeo b = yk_dbyte_geo(g, bi);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t t = b.t0 + (uint32_t)k;
+            tx[k] = b.bx0 + (int)((t & (uint32_t)b.tprMask) << g.sx); ty[k] = b.by0 + (int)((t >> b.tprShift) << g.sy);
+            const bool set = ((byte >> k) & 1u) && !(tx[k] + (1 << g.sx) > w || ty[k] + (1 << g.sy) > h);
+            const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
+            const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
+            o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
+            const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+            own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { own[k] = 0; tx[k] = 0; ty[k] = 0; }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cnt += (uint32_t)__popc(own[k]);
+        uint32_t tot, totW;
+        yk_block_exscan(cnt, s_tmp, &tot);
+        yk_block_exscan(wordSet ? 1u : 0u, s_tmp, &totW);
+        if (bi < nBytes) perThread[ti] = (uint8_t)cnt;
+        if (threadIdx.x == 0) { blockSums[blockIdx.x] = tot; blockWords[blockIdx.x] = totW; }
+        return;
+    }
+    uint32_t tot, totW;
+    const uint32_t ex = yk_block_exscan(cnt, s_tmp, &tot);
+    const uint32_t exW = yk_block_exscan(wordSet ? 1u : 0u, s_tmp, &totW);
+    if (wordSet) wordList[pl.wordStart[pass] + (blockWords[blockIdx.x] - blockWords[pl.blockStart[pass]]) + exW] = bi >> 2;
+    constexpr uint32_t kCap = 8192;                                          // colours listed per workgroup
+    __shared__ uint32_t s_li[kCap];
+    const uint32_t blockOff = (blockSums[blockIdx.x] - blockSums[pl.blockStart[pass]]) * 3u;
+    const uint8_t* const rgb = pl.rgb[pass];
+    const uint32_t rgbBytes = pl.rgbBytes[pass];
+    auto colour = [&](const uint32_t li, const uint32_t j) {                 // the j-th colour of the workgroup goes to lattice point li (:97-136)
+        const uint32_t off = blockOff + j * 3u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            uint32_t v = (off + ch < rgbBytes) ? rgb[off + ch] : 0u;
+            if (factor) v = (v * factor) >> 16;                              // PaletteFullRangeRemapping (YAIK_GenericFunctions.cpp:128-137)
+            mapRGB[(size_t)li * 3 + ch] = (uint8_t)v;
+        }
+        loaded[li] |= 1;
+    };
+    const bool viaLds = tot <= kCap;
+    if (cnt) {
+        uint32_t j = ex;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (!own[k]) continue;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                if (!((own[k] >> c4) & 1u)) continue;
+                const uint32_t li = (uint32_t)((ty[k] >> 2) + ((c4 & 2) ? dy : 0)) * (uint32_t)latW + (uint32_t)((tx[k] >> 2) + ((c4 & 1) ? dx : 0));
+                if (viaLds) s_li[j] = li; else colour(li, j);
+                j++;
+            }
+        }
+    }
+    if (!viaLds) return;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tot; j += 1024) colour(s_li[j], j);
+}
+
+// exclusive prefixes of both per-block arrays in place (one workgroup: thread t owns a run of consecutive blocks), words listed per pass
+__global__ __launch_bounds__(1024) void yk_decall_scan_kernel(uint32_t* __restrict__ blockSums, uint32_t* __restrict__ blockWords, const DecPlan pl, uint32_t* __restrict__ passWords) {
+    __shared__ uint32_t s_tmp[32];
+    __shared__ uint32_t s_totalW;
+    const uint32_t n = pl.blockStart[7], per = (n + 1023) / 1024;
+    const uint32_t a = min(threadIdx.x * per, n), b = min(a + per, n);
+    uint32_t sum = 0, sumW = 0;
+    for (uint32_t i = a; i < b; i++) { sum += blockSums[i]; sumW += blockWords[i]; }
+    uint32_t tot, totW;
+    uint32_t run = yk_block_exscan(sum, s_tmp, &tot);
+    uint32_t runW = yk_block_exscan(sumW, s_tmp, &totW);
+    for (uint32_t i = a; i < b; i++) {
+        const uint32_t v = blockSums[i], vw = blockWords[i];
+        blockSums[i] = run; run += v; blockWords[i] = runW; runW += vw;
+    }
+    if (threadIdx.x == 0) s_totalW = totW;
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const uint32_t lo = pl.blockStart[threadIdx.x] < n ? blockWords[pl.blockStart[threadIdx.x]] : s_totalW;
+        const uint32_t hi = pl.blockStart[threadIdx.x + 1] < n ? blockWords[pl.blockStart[threadIdx.x + 1]] : s_totalW;
+        passWords[threadIdx.x] = hi - lo;
+    }
+}
+
+// render of one pass from its list of non-empty bitmap words (a launch over every word of a sparse map is mostly workgroups that start and
+// leave: 336 k of them over the seven passes of an 8192 x 8192 frame)
+__global__ __launch_bounds__(256) void yk_decall_render_kernel(const uint8_t* __restrict__ bm, uint32_t nBytes, const uint32_t* __restrict__ wordList, const uint32_t* __restrict__ nListed,
+                                                               DPassGeo g, int w, int h, int latW, const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes,
+                                                               size_t planeSize, int tileW, uint32_t* __restrict__ tile4, int stride4) {
+    __shared__ DRenderLds L;
+    const uint32_t n = *nListed;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t wi = wordList[i], b0 = wi * 4u;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (b0 + j < nBytes) bits |= (uint32_t)bm[b0 + j] << (8 * j);
+        yk_dec_render_word(L, wi, bits, g, w, h, latW, mapRGB, planes, planeSize, tileW, tile4, stride4);
+        __syncthreads();
     }
 }
 
@@ -498,6 +693,78 @@ int yk_decode_gradient(yk_ctx* c, int sx, int sy, const uint8_t* bitmap, size_t 
 
 int yk_decode_gradient_device(yk_ctx* c, int sx, int sy, const uint8_t* devBitmap, size_t bitmapBytes, const uint8_t* devRgb, size_t rgbBytes, int remapRange) {
     return yk_decode_gradient_impl(c, sx, sy, devBitmap, bitmapBytes, devRgb, rgbBytes, true, remapRange);
+}
+
+int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX, const int* tileShiftY, const uint8_t* const* devBitmap, const size_t* bitmapBytes,
+                                  const uint8_t* const* devRgb, const size_t* rgbBytes, int remapRange) {
+    if (!c || nPasses < 0 || (nPasses && (!tileShiftX || !tileShiftY || !devBitmap || !bitmapBytes || !devRgb || !rgbBytes))) return YK_ERR_BAD_ARG;
+    if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
+    if (nPasses == 0) return YK_OK;
+    const int w = c->dw, h = c->dh, latW = w / 4 + 1;
+    const size_t lat = (size_t)latW * (h / 4 + 1);
+    static const int ok[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    bool oneCall = nPasses <= 7;
+    size_t need[7] = {};
+    for (int p = 0; p < nPasses; p++) {
+        bool found = false; for (auto& o : ok) found |= (o[0] == tileShiftX[p] && o[1] == tileShiftY[p]);
+        if (!found) return yk_fail(c, YK_ERR_BAD_ARG, "unsupported tile format");
+        if (!devBitmap[p]) return YK_ERR_BAD_ARG;
+        if (p < 7) {
+            const DPassGeo g = yk_dpass_geo(tileShiftX[p], tileShiftY[p], w);
+            need[p] = ((size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount) >> 3;
+            if (bitmapBytes[p] < need[p]) return yk_fail(c, YK_ERR_RANGE, "tile bitmap shorter than the image needs");
+            if (need[p] * 8 >= ((size_t)1 << 25) || rgbBytes[p] > 0xFFFFFFFFu) oneCall = false;      // the key holds 25 bits of tile position
+        }
+    }
+    if (!oneCall) {                                                          // very large images / more than seven chunks: pass after pass
+        for (int p = 0; p < nPasses; p++) {
+            const int rc = yk_decode_gradient_impl(c, tileShiftX[p], tileShiftY[p], devBitmap[p], bitmapBytes[p], devRgb[p], rgbBytes[p], true, remapRange);
+            if (rc) return rc;
+        }
+        return YK_OK;
+    }
+    YK_HIP(c, hipSetDevice(c->device));
+    DecPlan pl = {};
+    pl.n = nPasses;
+    for (int p = 0; p < 7; p++) {
+        const size_t nb = p < nPasses ? need[p] : 0;
+        pl.nBytes[p] = (uint32_t)nb; pl.rgbBytes[p] = p < nPasses ? (uint32_t)rgbBytes[p] : 0u;
+        pl.bm[p] = p < nPasses ? devBitmap[p] : nullptr; pl.rgb[p] = p < nPasses ? devRgb[p] : nullptr;
+        pl.sx[p] = p < nPasses ? tileShiftX[p] : 4; pl.sy[p] = p < nPasses ? tileShiftY[p] : 4;
+        pl.byteStart[p + 1] = pl.byteStart[p] + (uint32_t)nb;
+        pl.blockStart[p + 1] = pl.blockStart[p] + (uint32_t)((nb + 1023) / 1024);
+        pl.wordStart[p + 1] = pl.wordStart[p] + (uint32_t)((nb + 3) / 4);
+    }
+    const size_t nbTot = pl.blockStart[7], nBytesTot = pl.byteStart[7], nWordsTot = pl.wordStart[7];
+    // scratch: [corners per block | words per block | words listed per pass | corners per bitmap byte | render lists]
+    const size_t oS = 0, oW = oS + nbTot * 4, oP = oW + nbTot * 4, oT = oP + 64, oL = (oT + nBytesTot + 15) & ~(size_t)15;
+    { const int rc = yk_dec_scratch(c, oL + nWordsTot * 4 + 64); if (rc) return rc; }
+    uint8_t* S = c->dScratch;
+    uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oS);
+    uint32_t* blockWords = reinterpret_cast<uint32_t*>(S + oW);
+    uint32_t* passWords = reinterpret_cast<uint32_t*>(S + oP);
+    uint8_t* perThread = S + oT;
+    uint32_t* wordList = reinterpret_cast<uint32_t*>(S + oL);
+    const uint32_t factor = remapRange > 0 ? (uint32_t)((255u << 16) / (uint32_t)remapRange) : 0u;
+    YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
+    { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
+    // 1 clear + 4 launches for all passes + one render per pass (the per-pass form: 3 copies / clears + 5 launches per pass)
+    hipLaunchKernelGGL(yk_decall_owner_kernel, dim3((unsigned)((nBytesTot + 255) / 256)), dim3(256), 0, c->stream, pl, w, h, latW, c->dLoaded, c->dLatticeOwner);
+    hipLaunchKernelGGL(yk_decall_stream_kernel<false>, dim3((unsigned)nbTot), dim3(1024), 0, c->stream, pl, w, h, latW, c->dLoaded, c->dLatticeOwner, blockSums, blockWords,
+                       perThread, (uint8_t*)nullptr, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(yk_decall_scan_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, blockWords, pl, passWords);
+    hipLaunchKernelGGL(yk_decall_stream_kernel<true>, dim3((unsigned)nbTot), dim3(1024), 0, c->stream, pl, w, h, latW, c->dLoaded, c->dLatticeOwner, blockSums, blockWords,
+                       perThread, c->dMapRGB, wordList, factor);
+    for (int p = 0; p < nPasses; p++) {                                      // in call order: a later, overlapping tile overwrites an earlier one like the reference
+        const DPassGeo g = yk_dpass_geo(pl.sx[p], pl.sy[p], w);
+        const size_t words = (pl.nBytes[p] + 3) / 4;
+        const unsigned grid = (unsigned)(words < 8192 ? (words ? words : 1) : 8192);
+        hipLaunchKernelGGL(yk_decall_render_kernel, dim3(grid), dim3(256), 0, c->stream, pl.bm[p], pl.nBytes[p], wordList + pl.wordStart[p], passWords + p, g, w, h, latW,
+                           c->dMapRGB, c->dPlanes, c->dPlaneSize, w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
+    }
+    YK_HIP(c, hipGetLastError());
+    { int rc2 = yk_stage_end(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
+    return YK_OK;
 }
 
 static int yk_dec_split(yk_ctx* c) {                                       // UpdateTileAndRGBMask (YAIK_API.cpp:530-544), once

@@ -59,20 +59,30 @@ class HipTileDecoder:
         enc.synchronize()
         return calls
 
-    def decode_streams(self, calls: list, sync: bool = True) -> None:
+    def decode_streams(self, calls: list, sync: bool = True, per_pass: bool = False) -> None:
         """All gradient chunks + the 1-D chunk from device-resident streams (encoder_streams): the corner streams are remapped like
-        PaletteFullRangeRemapping(250) on the way in; no PCIe hop, no host synchronisation between the passes."""
+        PaletteFullRangeRemapping(250) on the way in; no PCIe hop, no host synchronisation between the passes.  The gradient chunks go through
+        ONE yk_decode_gradient_all_device call (per_pass=True: one yk_decode_gradient_device call per chunk, same result)."""
         L = lib()
-        for c in calls:
-            if c[0] == "g":
+        g = [c for c in calls if c[0] == "g"]
+        if per_pass:
+            for c in g:
                 _chk(self._h, L.yk_decode_gradient_device(self._h, c[1], c[2], c[3], c[4], c[5], c[6], 250))
-            else:
+        elif g:
+            n = len(g)
+            ptr = lambda v: v.value if isinstance(v, C.c_void_p) else v
+            sx, sy = (C.c_int * n)(*[c[1] for c in g]), (C.c_int * n)(*[c[2] for c in g])
+            bm, nb = (C.c_void_p * n)(*[ptr(c[3]) for c in g]), (C.c_size_t * n)(*[c[4] for c in g])
+            rgb, nr = (C.c_void_p * n)(*[ptr(c[5]) for c in g]), (C.c_size_t * n)(*[c[6] for c in g])
+            _chk(self._h, L.yk_decode_gradient_all_device(self._h, n, sx, sy, bm, nb, rgb, nr, 250))
+        for c in calls:
+            if c[0] == "1":
                 _chk(self._h, L.yk_decode_1d_device(self._h, c[1], c[2], c[3], c[4], 15))
         if sync:
             _chk(self._h, L.yk_synchronize(self._h))
 
-    def decode_from_encoder(self, enc, sync: bool = True) -> None:
-        self.decode_streams(self.encoder_streams(enc), sync)
+    def decode_from_encoder(self, enc, sync: bool = True, per_pass: bool = False) -> None:
+        self.decode_streams(self.encoder_streams(enc), sync, per_pass)
 
     def decompress_gradient_planes(self, plane_bit: int, bitmap: np.ndarray, rgb_dq: np.ndarray, consistent_marks: bool = False):
         """DecompressGradient4x4 with planeBit 1..6; consistent_marks=False leaves tile4x4Mask as the reference's loops do (defects included)."""
