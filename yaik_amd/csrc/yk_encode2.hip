@@ -99,7 +99,7 @@ template <int SX, int SY, bool SMOOTH = false>
 __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int lat, const int cx, const int cy,
                                              const uint32_t (&pwb)[16], unsigned long long& cov, const unsigned long long deadLanes, const bool stripInside,
                                              const int gxCell, const int gyCell, const int w, const int h, const int rf,
-                                             uint32_t* s_bm, const int bxCell, const int byCell, const uint32_t* s_pix, uint8_t* s_list, const int lane) {
+                                             uint32_t* s_bm, const int bxCell, const int byCell, const uint32_t* s_pix, uint8_t* s_list, uint32_t* s_tf, const int lane) {
     constexpr int TX = 1 << SX, TY = 1 << SY, NX = TX / 4, NY = TY / 4;
     constexpr unsigned long long ORG = y2_origin<NX, NY>();
     const int dcx = cx & (NX - 1), dcy = cy & (NY - 1);                  // this cell's offset inside its tile, in cells
@@ -119,8 +119,9 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
 #ifndef YK2_NO_COMPACT
     // ---- few viable cells (a strip whose larger tiles failed along an edge, the usual case next to contours): a pass over 64 lanes
     // would keep at most a quarter of them busy for four rows.  Instead lane (j, r) = (j-th viable cell, row r of it) evaluates ONE row
-    // of a viable cell, all five streams; the pixels come from the staged strip in LDS.  Decisions go back to the cells' own lanes
-    // through ballots, so everything after the evaluation is the same as in the full pass.
+    // of a viable cell; the pixels come from the staged strip in LDS.  A lane's failures are six bits (one per variant) OR-ed into a
+    // word of its tile in LDS; a tile is lost when all six are set.  Two stages like the full pass: streams {0, 3} first (a tile whose
+    // far corners sit on other content fails there), the other three only for waves that still hold a tile afterwards.
     const unsigned long long cells = y2_spread<NX, NY>(viable);
     const int nCells = __popcll(cells);
     if (nCells <= 16) {
@@ -128,61 +129,77 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cells >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cells, 0u));
         const bool mine = __builtin_amdgcn_inverse_ballot_w64(cells);
         if (mine) s_list[rank] = (uint8_t)lane;
+        s_tf[lane] = 0u; s_tf[64 + lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int j = lane & 15, r = lane >> 4;
         const bool act = j < nCells;
         const int c = (int)s_list[act ? j : 0];
         const int q2 = c >> 4, cy2 = y2_cell_y(c & 15), cx2 = y2_cell_x(c & 15);
         const int dcx2 = cx2 & (NX - 1), dcy2 = cy2 & (NY - 1);
+        constexpr int kInTile = (NX > 1 ? 1 : 0) | (NY > 1 ? 2 : 0) | (NX > 2 ? 4 : 0) | (NY > 2 ? 8 : 0);   // Morton bits of a cell inside its tile
+        const int orig = c & ~kInTile;                                       // lane of the tile's origin cell
         const int lo2 = cy2 * 17 + q2 * 4 + cx2 - dcy2 * 17 - dcx2;          // lattice index of the tile origin
         const y2u2 wyr = y2_splat(16 - ((dcy2 * 4 + r) << (4 - SY)));       // weight of row r of the cell
         const y2u2 lxc = y2_splat(16 - ((dcx2 * 4) << (4 - SX)));           // weight of the cell's first pixel column
         const uint4 pr = *reinterpret_cast<const uint4*>(&s_pix[(cy2 * 4 + r) * LS + q2 * 16 + cx2 * 4]);
         const uint32_t px[4] = { pr.x ^ 0x00808080u, pr.y ^ 0x00808080u, pr.z ^ 0x00808080u, pr.w ^ 0x00808080u };   // bias of the packed arithmetic
-        y2u2 Sc[5], stc[5];
-#pragma unroll
-        for (int t = 0; t < 5; t++) {
-            const uint32_t* lt = s_lat + t * YK2_LATN + lo2;
-            const y2u2 TL = y2_u2(lt[0]), TR = y2_u2(lt[NX]), BL = y2_u2(lt[NY * 17]), BR = y2_u2(lt[NY * 17 + NX]);
-            const y2u2 e16 = (BL - BR) << 4, g = TR - BR, f = TL - BL - g;
-            const y2u2 c2 = (g << 4) + f * lxc;
-            Sc[t] = ((BR << 8) + e16 * lxc + c2 * wyr) ^ y2_splat(0x8000);   // S'(x0, row r), biased
-            stc[t] = (e16 + f * wyr) << (4 - SX);                            // S'(x, r) - S'(x+1, r)
-        }
         y2s2 mnc[5], mxc[5];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t p = px[i];
-            const y2s2 c01 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))), c22 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu)));
-            const y2s2 cc[4] = { __builtin_shufflevector(c01, c01, 0, 0), __builtin_shufflevector(c01, c01, 1, 1), c22, c01 };
+        auto rowC = [&](const unsigned mask) {                               // the row's four pixels for the streams in `mask`
+            y2u2 Sc[5], stc[5];
 #pragma unroll
             for (int t = 0; t < 5; t++) {
-                const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(Sc[t]), cc[t == 4 ? 2 : t]);
-                if (i == 0) { mnc[t] = D; mxc[t] = D; }
-                else { mnc[t] = __builtin_elementwise_min(mnc[t], D); mxc[t] = __builtin_elementwise_max(mxc[t], D); }
-                if (i < 3) Sc[t] = Sc[t] - stc[t];
+                if (!((mask >> t) & 1u)) continue;
+                const uint32_t* lt = s_lat + t * YK2_LATN + lo2;
+                const y2u2 TL = y2_u2(lt[0]), TR = y2_u2(lt[NX]), BL = y2_u2(lt[NY * 17]), BR = y2_u2(lt[NY * 17 + NX]);
+                const y2u2 e16 = (BL - BR) << 4, g = TR - BR, f = TL - BL - g;
+                const y2u2 c2 = (g << 4) + f * lxc;
+                Sc[t] = ((BR << 8) + e16 * lxc + c2 * wyr) ^ y2_splat(0x8000);   // S'(x0, row r), biased
+                stc[t] = (e16 + f * wyr) << (4 - SX);                            // S'(x, r) - S'(x+1, r)
             }
-        }
-        const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mnc[0], mnc[1]), mnc[2]), mxA = __builtin_elementwise_max(__builtin_elementwise_max(mxc[0], mxc[1]), mxc[2]);
-        const y2s2 mnP = __builtin_elementwise_min(mnc[3], mnc[4]), mxP = __builtin_elementwise_max(mxc[3], mxc[4]);
-        const y2s2 oA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2));
-        const y2s2 rA = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2));
-        const y2s2 oP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2));
-        const y2s2 rP = __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2));
-        // failing (cell, row) lanes per variant -> OR over the four rows (bits 16 r + j -> bit j) -> back to the cells' own lanes by their rank
-        auto toCells = [&](const bool fail) -> unsigned long long {
-            unsigned long long b = __ballot(fail && act);
-            b |= b >> 16; b |= b >> 32;
-            const uint32_t e = (uint32_t)b & 0xFFFFu;
-            return __ballot(mine && ((e >> rank) & 1u));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t p = px[i];
+                const y2s2 c01 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x010C000Cu))), c22 = y2_s2(y2_u2(__builtin_amdgcn_perm(0u, p, 0x020C020Cu)));
+                const y2s2 cc[4] = { __builtin_shufflevector(c01, c01, 0, 0), __builtin_shufflevector(c01, c01, 1, 1), c22, c01 };
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    if (!((mask >> t) & 1u)) continue;
+                    const y2s2 D = __builtin_elementwise_sub_sat(y2_s2(Sc[t]), cc[t == 4 ? 2 : t]);
+                    if (i == 0) { mnc[t] = D; mxc[t] = D; }
+                    else { mnc[t] = __builtin_elementwise_min(mnc[t], D); mxc[t] = __builtin_elementwise_max(mxc[t], D); }
+                    if (i < 3) Sc[t] = Sc[t] - stc[t];
+                }
+            }
         };
-        unsigned long long f = y2_fold<NX, NY>(toCells(oA.x > 0));
-        f &= y2_fold<NX, NY>(toCells(oA.y > 0));
-        f &= y2_fold<NX, NY>(toCells(rA.x > 0));
-        f &= y2_fold<NX, NY>(toCells(rA.y > 0));
-        f &= y2_fold<NX, NY>(toCells((oP.x > 0) | (oP.y > 0)));
-        f &= y2_fold<NX, NY>(toCells((rP.x > 0) | (rP.y > 0)));
-        const unsigned long long acceptC = viable & ~f;                      // some variant never failed (:3998)
+        // the lane's failing variants as bits 31, 30 (raw / Round6 corners without the rounding term), 15, 14 (with it), 29, 13 (Round6P corners)
+        constexpr uint32_t kAllFail = 0xE000E000u;
+        auto failBits = [&](const y2s2 mnA, const y2s2 mxA, const y2s2 mnP, const y2s2 mxP) -> uint32_t {
+            const y2s2 zero = y2_splats(0);
+            // a half is negative when its variant has a pixel outside the window (x = raw corners, y = Round6 corners)
+            const y2s2 oA = __builtin_elementwise_sub_sat(zero, __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnA), __builtin_elementwise_sub_sat(mxA, hiO2)));
+            const y2s2 rA = __builtin_elementwise_sub_sat(zero, __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnA), __builtin_elementwise_sub_sat(mxA, hiR2)));
+            const y2s2 oP = __builtin_elementwise_sub_sat(zero, __builtin_elementwise_max(__builtin_elementwise_sub_sat(loO2, mnP), __builtin_elementwise_sub_sat(mxP, hiO2)));
+            const y2s2 rP = __builtin_elementwise_sub_sat(zero, __builtin_elementwise_max(__builtin_elementwise_sub_sat(loR2, mnP), __builtin_elementwise_sub_sat(mxP, hiR2)));
+            const uint32_t a = __builtin_bit_cast(uint32_t, oA), b = __builtin_bit_cast(uint32_t, rA), cO = __builtin_bit_cast(uint32_t, oP), cR = __builtin_bit_cast(uint32_t, rP);
+            // raw-O -> bit 15, Round6-O -> bit 31, raw-R -> 14, Round6-R -> 30, Round6P-O (either half) -> 29, Round6P-R -> 13
+            uint32_t m = (a & 0x80008000u) | ((b >> 1) & 0x40004000u);
+            m |= (((cO << 16) | cO) >> 2) & 0x20000000u;
+            m |= (((cR >> 16) | cR) >> 2) & 0x00002000u;
+            return m;
+        };
+        rowC(0x09u);
+        if (act) atomicOr(&s_tf[orig], failBits(mnc[0], mxc[0], mnc[3], mxc[3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long alive = viable & __ballot(s_tf[lane] != kAllFail);
+        if (alive == 0ULL) return;
+        rowC(0x16u);
+        {
+            const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mnc[0], mnc[1]), mnc[2]), mxA = __builtin_elementwise_max(__builtin_elementwise_max(mxc[0], mxc[1]), mxc[2]);
+            const y2s2 mnP = __builtin_elementwise_min(mnc[3], mnc[4]), mxP = __builtin_elementwise_max(mxc[3], mxc[4]);
+            if (act) atomicOr(&s_tf[64 + orig], failBits(mnA, mxA, mnP, mxP));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long acceptC = alive & __ballot(s_tf[64 + lane] != kAllFail);   // some variant never failed (:3998)
         if (acceptC != 0ULL) {
             cov |= y2_spread<NX, NY>(acceptC);
             if (__builtin_amdgcn_inverse_ballot_w64(acceptC)) {
@@ -711,15 +728,15 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;                // bias of the packed passes (bytes - 128)
-            if (deadLanes == 0ULL) y2_grad_pass<4, 4, true>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-            else y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+            if (deadLanes == 0ULL) y2_grad_pass<4, 4, true>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+            else y2_grad_pass<4, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
             if (~(cov | deadLanes) != 0ULL) {
-                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
-                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, lane);
+                y2_grad_pass<4, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+                y2_grad_pass<3, 4>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+                y2_grad_pass<3, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+                y2_grad_pass<3, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+                y2_grad_pass<2, 3>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
+                y2_grad_pass<2, 2>(s_lat, lat, cx, cy, pw, cov, deadLanes, stripInside, gxCell, gyCell, w, h, P.rejectFactor, s_bm, bxCell, byCell, s_pix, s_list, s_range, lane);
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
