@@ -40,5 +40,8 @@ for p in range(7):
     e = max(r[0], 1.0)
     print(f"{names[p]:6s} {r[0] / n:7.3f} {r[1] / n:7.3f} {r[2] / n:7.3f} {r[3] / n:7.3f} {r[9] / n:7.3f} {r[4] / n:7.3f} {r[5] / n:7.3f} {r[6] / n:7.3f} "
           f"{r[8] / e:8.1f} {r[7] / max(r[1], 1):8.1f} {float(st[90 + p]) / max(r[5], 1):8.1f}")
+print("compact: exits after stage 1 per strip", [round(float(st[100 + p]) / n, 3) for p in range(7)], " accepts", [round(float(st[110 + p]) / n, 3) for p in range(7)])
+print("smooth 16x16 strips: tiles viable / accepted by raw|Round6 / by Round6P / by either, per strip:", [round(float(st[i]) / n, 3) for i in (107, 97, 98, 99)])
+print("valid lanes per strip (0, 1-4, 5-8, 9-16, 17-32, 33-63, 64):", [round(float(st[120 + i]) / n, 3) for i in range(7)])
 print(f"range: strips coded {st[70] / n:.3f}, valid lanes per coded strip {st[74] / max(float(st[70]), 1):.1f}, plane-waves with ambiguous tiles {st[71] / n:.4f} "
       f"(tiles {st[72] / n:.4f} per strip), tie blocks {st[73] / n:.4f} per strip")

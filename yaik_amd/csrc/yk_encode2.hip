@@ -191,7 +191,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         if (act) atomicOr(&s_tf[orig], failBits(mnc[0], mxc[0], mnc[3], mxc[3]));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long alive = viable & __ballot(s_tf[lane] != kAllFail);
-        if (alive == 0ULL) return;
+        if (alive == 0ULL) { YK2_STAT(100 + kPassId, 1); return; }
         rowC(0x16u);
         {
             const y2s2 mnA = __builtin_elementwise_min(__builtin_elementwise_min(mnc[0], mnc[1]), mnc[2]), mxA = __builtin_elementwise_max(__builtin_elementwise_max(mxc[0], mxc[1]), mxc[2]);
@@ -201,6 +201,7 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long acceptC = alive & __ballot(s_tf[64 + lane] != kAllFail);   // some variant never failed (:3998)
         if (acceptC != 0ULL) {
+            YK2_STAT(110 + kPassId, 1);
             cov |= y2_spread<NX, NY>(acceptC);
             if (__builtin_amdgcn_inverse_ballot_w64(acceptC)) {
                 const int tbx = bxCell >> SX, tby = byCell >> SY;
@@ -302,6 +303,18 @@ __device__ __forceinline__ void y2_grad_pass(const uint32_t* s_lat, const int la
         nextRow(2, kA); pixelRow(3, kA, false);
         YK2_STAT(kPassId * 10 + 4, 1);
         accept = viable & ~failA4(mnAll(), mxAll());
+#ifdef YK2_STATS
+        {   // which variants accept the tiles of smooth strips (never shipped)
+            y2u2 S_[5], st_[5], a_[5], b_[5], c_[5]; y2s2 mn_[5], mx_[5];
+            for (int t = 0; t < 5; t++) { S_[t] = S[t]; st_[t] = st[t]; a_[t] = dS0[t]; b_[t] = dS3[t]; c_[t] = dst[t]; mn_[t] = mn[t]; mx_[t] = mx[t]; }
+            setup(3); setup(4);
+            pixelRow(0, kP, true); nextRow(0, kP); pixelRow(1, kP, false); nextRow(1, kP); pixelRow(2, kP, false); nextRow(2, kP); pixelRow(3, kP, false);
+            const unsigned long long accP = viable & ~failP2(__builtin_elementwise_min(mn[3], mn[4]), __builtin_elementwise_max(mx[3], mx[4]));
+            YK2_STAT(97, __popcll(accept)); YK2_STAT(98, __popcll(accP)); YK2_STAT(99, __popcll(accept | accP)); YK2_STAT(96 + 0 * kPassId, 0);
+            YK2_STAT(107, __popcll(viable));
+            for (int t = 0; t < 5; t++) { S[t] = S_[t]; st[t] = st_[t]; dS0[t] = a_[t]; dS3[t] = b_[t]; dst[t] = c_[t]; mn[t] = mn_[t]; mx[t] = mx_[t]; }
+        }
+#endif
         const unsigned long long rest = viable & ~accept;
         if (rest != 0ULL) {
             YK2_STAT(kPassId * 10 + 5, 1); YK2_STAT(90 + kPassId, __popcll(y2_spread<NX, NY>(rest)));
@@ -520,6 +533,14 @@ template <int FIRST> __device__ __forceinline__ void y2_quad_sums(float (&t)[6])
 #undef Y2_QX
 #undef Y2_QY
 }
+// sum of a value over the 16 lanes of a DPP row (every lane ends with the same total: each step adds mirror-image partners)
+__device__ __forceinline__ float y2_row16_sum(float x) {
+    x = __fadd_rn(x, y2_quad<Y2_QUAD_X>(x));
+    x = __fadd_rn(x, y2_quad<Y2_QUAD_Y>(x));
+    x = __fadd_rn(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+    x = __fadd_rn(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true)));   // row_mirror
+    return x;
+}
 // 4 * byte `ch` of w in one instruction (SDWA byte select feeding the shift)
 __device__ __forceinline__ uint32_t y2_byte_x4(uint32_t w, int ch) {
     uint32_t r; const uint32_t two = 2u;
@@ -561,6 +582,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     float (*const s_chain)[68] = reinterpret_cast<float (*)[68]>(s_aux);
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
     __shared__ uint32_t s_range[3 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_sp[3 * 4 * 8 + 3 * 4 * 16];      // strips with at most four cells to code: six sums and sixteen index words per plane and cell
     uint32_t* const s_tile = s_aux + 416;                                    // exact-order fallback: the 64 values of the tile-plane being re-summed
     // range phase: the index words of a plane's sixteen rows per lane; the staged pixels are dead by then (the test build's LUTs live there)
     __shared__ uint32_t s_iwTest[WANT_DST ? 1024 : 1];
@@ -828,6 +850,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     }
 
     YK2_STAT(70, validMask != 0ULL ? 1 : 0); YK2_STAT(74, __popcll(validMask));
+    { const int nv = __popcll(validMask); YK2_STAT(120 + (nv == 0 ? 0 : nv <= 4 ? 1 : nv <= 8 ? 2 : nv <= 16 ? 3 : nv <= 32 ? 4 : nv < 64 ? 5 : 6), 1); (void)nv; }
     if (validMask == 0ULL || YK2_ABLATE(1)) {
         if (writer) {
 #pragma unroll
@@ -841,6 +864,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             if (lane < 32) s_curve[4 + (lane >> 4)][lane & 15] = c_curve2[4 + (lane >> 4)][lane & 15];
         }
         const int j4 = lane & 3;                                             // lane index inside its tile (cellY&1)*2 + (cellX&1)
+        // ---- at most four cells to code (a smooth strip's last column of cells next to other content, the usual case along contours): 61 idle
+        // lanes would watch them walk sixteen pixels each.  Instead the sixteen lanes of a DPP row take one pixel each of one of those cells
+        // (`spread`); the cells' own lanes get the six sums back through LDS and carry on as if they had walked the pixels themselves.
+        const int nValidLanes = __popcll(validMask);
+        const bool spread = nValidLanes <= 4 && !WANT_DST;
+        const int vRank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(validMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)validMask, 0u));
         uint32_t slotOff[4];                                                 // byte offset of the lane's four nibble rows inside the plane's slot array
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -887,10 +916,40 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         // the quantiser table's rows start 256 rows before the table (the row base of the definition table is biased by +256)
         const uint8_t* const qrows = P.qtab - (size_t)256 * 16;
+        if (spread && !YK2_ABLATE(4)) {
+            // lane (i, k) = pixel k of the i-th cell to code, the three planes one after the other: ONE row and six products per lane and plane, the
+            // sums over the sixteen lanes of the row by DPP; sums and index words wait in LDS for the cell's own lane
+            if (valid) s_list[vRank] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int spI = lane >> 4, spK = lane & 15;                      // pixel of the cell: row spK >> 2, column spK & 3
+            const bool spAct = spI < nValidLanes;
+            const int spSrc = (int)s_list[spAct ? spI : 0];
+            const int sq = spSrc >> 4, scx = y2_cell_x(spSrc & 15), scy = y2_cell_y(spSrc & 15);
+            const uint32_t spx = s_pix[(scy * 4 + (spK >> 2)) * LS + sq * 16 + scx * 4 + (spK & 3)];   // the staged strip is intact until the first index word is parked
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const uint32_t q16s = (uint32_t)__builtin_amdgcn_ds_bpermute(spSrc << 2, (int)((tdef[p] & 0xFFFFu) << 4));   // the row base of the source cell's tile
+                float t6[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+                if (spAct) {
+                    const uint32_t v4 = y2_byte_x4(spx, p);
+                    const uint4 row = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + q16s));
+                    const float rv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_rcp) + v4);
+                    if (!MODE3) { y2_fma_lo(t6[0], row.x, rv); y2_fma_hi(t6[1], row.x, rv); y2_fma_lo(t6[2], row.y, rv); }
+                    y2_fma_hi(t6[3], row.y, rv); y2_fma_lo(t6[4], row.z, rv); y2_fma_hi(t6[5], row.z, rv);
+                    s_sp[96 + (p * 4 + spI) * 16 + spK] = row.w;
+                }
+#pragma unroll
+                for (int m = kStart; m < 6; m++) {
+                    const float tot = y2_row16_sum(t6[m]);
+                    if (spK == 0) s_sp[(p * 4 + spI) * 8 + m] = __float_as_uint(tot);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         // ---- nearest LUT entry per pixel and mode: ONE 16-byte row of the quantiser table per pixel and plane, all sixteen of a plane in flight at once
         uint4 win[16];
         auto issueRows = [&](const int pl, const int k0, const int k1) {
-            if (valid && !YK2_ABLATE(4)) {
+            if (valid && !spread && !YK2_ABLATE(4)) {
                 const uint32_t q16 = (tdef[pl] & 0xFFFFu) << 4;
 #pragma unroll
                 for (int k = k0; k < k1; k++) {
@@ -916,7 +975,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             const uint32_t qrow16 = (tdef[p] & 0xFFFFu) << 4;               // byte offset of the row of v = 0 behind qrows
             float sm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             issueRows(p, YK2_PREF, 16);                                       // the rows that were not sent ahead
-            if (valid && !YK2_ABLATE(4)) {
+            if (valid && !spread && !YK2_ABLATE(4)) {
                 // The plane's sixteen rows are in flight already (issued before the previous plane's mode selection, see below); the index
                 // words wait in LDS (word = pixel * 64 + lane: conflict-free) until the mode is chosen.
                 float rvw[YK2_RVWIN];
@@ -935,6 +994,15 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     if (k + YK2_RVWIN < 16) issueRcp(k + YK2_RVWIN, rvw[k % YK2_RVWIN]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (spread && valid && !YK2_ABLATE(4)) {                          // the sums and index words the spread lanes left for this cell
+#pragma unroll
+                for (int m = kStart; m < 6; m++) sm[m] = __uint_as_float(s_sp[(p * 4 + vRank) * 8 + m]);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const uint4 iw4 = *reinterpret_cast<const uint4*>(&s_sp[96 + (p * 4 + vRank) * 16 + k4 * 4]);
+                    s_iw[(k4 * 4 + 0) * 64 + lane] = iw4.x; s_iw[(k4 * 4 + 1) * 64 + lane] = iw4.y; s_iw[(k4 * 4 + 2) * 64 + lane] = iw4.z; s_iw[(k4 * 4 + 3) * 64 + lane] = iw4.w;
+                }
             }
             // the first rows of the next plane leave now: their round trip runs under this plane's mode selection, nibble packing and stores
             if (p < 2) issueRows(p + 1, 0, YK2_PREF);
