@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 from oracle.refrun import have_ref, run_reference  # noqa: E402
 from tests.blobs import LUT_KEEP, PP_KEEP  # noqa: E402
-from tests.lutbank import bank_bytes, bank_patterns, lut_image  # noqa: E402
+from tests.lutbank import bank16, bank_bytes, bank_patterns, lut_image, lut_image_rgba  # noqa: E402
 from tests.images import edge_image, lineart_image, natural_photo, synth_planes  # noqa: E402
 
 PHOTO_SRC = "/opt/conda/lib/python3.9/site-packages/skimage/data/astronaut.png"       # present in the build image; never read by tests
@@ -49,6 +49,7 @@ PARTIAL = {  # name -> planes factory; `ref_driver ... partial` (six partial-pla
 LUT3D = {  # name -> (planes, patterns); `ref_driver ... lut3d <bank>` with the synthetic bank of tests/lutbank.py: streams + maps + 1-D blobs
     "lut_lutmix128_rgb": lambda: (lut_image(128, 128, seed=3), bank_patterns()),
     "lut_lutmix192x144_rgb": lambda: (lut_image(192, 144, seed=7), bank_patterns()),
+    "lut_lutmix256_rgba_bank16": lambda: (lut_image_rgba(256, 256, bank16(), seed=9), bank16()),     # 16 patterns, alpha plane in front
 }
 # blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
 DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_")
@@ -66,6 +67,14 @@ def write_photo_input():
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None                # `make_golden.py <lut fixture name>`: that fixture alone
+    if only in LUT3D:
+        planes, pats = LUT3D[only]()
+        blobs = run_reference(planes, lut_bank=bank_bytes(pats))
+        keep = {k: np.frombuffer(v, dtype=np.uint8) for k, v in blobs.items() if k.startswith(LUT_KEEP)}
+        np.savez_compressed(os.path.join(HERE, only + ".npz"), **keep)
+        print(only, sum(v.size for v in keep.values()), "bytes raw")
+        return 0
     write_photo_input()
     if not have_ref():
         print("oracle/_ref/ref_driver is missing: run `make -C oracle` on a machine that has /root/reference", file=sys.stderr)

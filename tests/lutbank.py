@@ -64,3 +64,16 @@ def random_bank(seed: int, n_patterns: int = 5) -> list:
             p = c[rng.integers(0, 4, n)] + rng.integers(-6, 7, (n, 3))
         pats.append(np.clip(np.floor(p + 0.5), 0, 63).astype(np.uint8))
     return pats
+
+
+def bank16() -> list:
+    """Sixteen patterns: the six designed curves + ten of the random kind (point counts 1..64, unordered, duplicated, clustered)."""
+    return bank_patterns() + random_bank(7, 10)
+
+
+def lut_image_rgba(w: int, h: int, patterns=None, seed: int = 3) -> np.ndarray:
+    """lut_image plus an alpha plane: transparent frame and holes on the 16x16 grid (the alpha tile-reject in front of the LUT search)."""
+    rgb = lut_image(w, h, patterns, seed)
+    y, x = np.mgrid[0:h, 0:w]
+    hole = (x < 16) | (y >= h - 32) | ((((x >> 4) + 2 * (y >> 4)) % 7) == 0)
+    return np.ascontiguousarray(np.concatenate([rgb, np.where(hole, 0, 255).astype(np.int32)[None]]))

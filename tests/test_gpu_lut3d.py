@@ -120,6 +120,8 @@ def test_lut_search_matches_reference_fixture(hip, name):
     for p in pats:
         hip.lut_load(p)
     hip.set_image(planes)
+    if planes.shape[0] == 4:
+        hip.mip_prefilter()
     hip.encode(3, False, False)
     hip.lut_start()
     counts = np.frombuffer(ref["lut_counts"].tobytes(), np.int32).reshape(6, 6)

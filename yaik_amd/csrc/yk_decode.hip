@@ -504,7 +504,8 @@ __global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restric
     __syncthreads();
     const int j = threadIdx.x & 3, half = j >> 1, rp = j & 1;
     uint8_t* const plane = planes + (size_t)p * planeSize;
-#pragma unroll 1
+    // unrolled: the four tiles' loads are independent of each other's stores (restrict), so all of a lane's stream reads are in flight together
+#pragma unroll
     for (int it = 0; it < 4; it++) {
         const int t = it * 256 + (threadIdx.x >> 2);
         const size_t i = i0 + t;

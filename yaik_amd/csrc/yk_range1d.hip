@@ -24,7 +24,9 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     // onlyPlane < 0: the three planes share `coverage` (no partial-plane pass ran).  Otherwise this launch codes plane `onlyPlane` alone
     // against that plane's own coverage (mapSmoothTile->GetPlane(p), EncoderContext.cpp:9451-9465).
     __shared__ __attribute__((aligned(16))) uint32_t s_px[16 * 16];          // 16 rows x 64 pixels, one byte each
-    __shared__ __attribute__((aligned(16))) uint32_t s_hist[16 * 64];        // per tile: 256 byte-wide bins
+    // per tile: 256 byte-wide bins in 64 words; the tiles' histograms are 65 words apart: neighbouring tiles hold similar values, and with a
+    // stride of 64 the same bin of every tile sat in one LDS bank (the sixteen ds_add of a lane then serialised across the whole wave)
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[16 * 65 + 16];
     const int lane = threadIdx.x;
     const int xBB = (w + 63) >> 6;
     const int BX = (int)(blockIdx.x % xBB), SY = (int)(blockIdx.x / xBB);    // strip coordinates (64 px, 16 rows)
@@ -44,9 +46,10 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     const size_t ti = (size_t)(tgy >> 3) * tilesW + (tgx >> 3);
     const bool writer = tileIn && cxl == 0 && cyl == 0;
     if (writer) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
-    if (__ballot(valid) == 0ULL) return;
+    const unsigned long long validCells = __ballot(valid);                   // bit = lane = macroTile * 16 + cellY * 4 + cellX
+    if (validCells == 0ULL) return;
     const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the strip
-    uint32_t* hist = &s_hist[tw * 64];
+    uint32_t* hist = &s_hist[tw * 65];
     // position of the lane's pixel rows among the tile's emitted pixels: top half rows (left then right quadrant), then bottom (:8420-8453)
     const int posBase = cyl ? (16 * nTop + (cxl ? 4 * (int)u01 : 0)) : (cxl ? 4 * (int)u00 : 0);
     const int posStep = 4 * (cyl ? nBot : nTop);
@@ -61,7 +64,10 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             for (int k = 0; k < 4; k++) {
                 const int gy = SY * 16 + r0 + 4 * k;
                 int4 v = make_int4(0, 0, 0, 0);
-                if (gx + 3 < w && gy < h) v = *reinterpret_cast<const int4*>(planes[p] + (size_t)gy * strideElems + gx);
+                // only the row segments of cells that are coded are fetched (a smooth strip next to a contour has 4 of its 64 cells left:
+                // 768 bytes instead of 12 KB); segment (lane & 15) of row r0 + 4k lies in cell (x = lane & 3, y = k) of macro-tile (lane >> 2) & 3
+                const bool need = (validCells >> ((((lane >> 2) & 3) << 4) + (k << 2) + (lane & 3))) & 1ULL;
+                if (need && gx + 3 < w && gy < h) v = *reinterpret_cast<const int4*>(planes[p] + (size_t)gy * strideElems + gx);
                 pk[k] = ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);   // CompressF(v,255) == v
             }
             __syncthreads();                                                 // previous plane's readers are done (single wave: LDS fence)
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 4]) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 8]) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 12]) = make_uint4(0, 0, 0, 0);
+            if (lane < 4) *reinterpret_cast<uint4*>(&s_hist[1024 + lane * 4]) = make_uint4(0, 0, 0, 0);
             __syncthreads();
         }
         uint32_t row[4];
