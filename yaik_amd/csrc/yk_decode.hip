@@ -709,7 +709,7 @@ int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX,
     for (int p = 0; p < nPasses; p++) {
         bool found = false; for (auto& o : ok) found |= (o[0] == tileShiftX[p] && o[1] == tileShiftY[p]);
         if (!found) return yk_fail(c, YK_ERR_BAD_ARG, "unsupported tile format");
-        if (!devBitmap[p]) return YK_ERR_BAD_ARG;
+        if (!devBitmap[p] || (rgbBytes[p] && !devRgb[p])) return YK_ERR_BAD_ARG;
         if (p < 7) {
             const DPassGeo g = yk_dpass_geo(tileShiftX[p], tileShiftY[p], w);
             need[p] = ((size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount) >> 3;

@@ -48,6 +48,69 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     if (writer) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
     const unsigned long long validCells = __ballot(valid);                   // bit = lane = macroTile * 16 + cellY * 4 + cellX
     if (validCells == 0ULL) return;
+    // ---- at most four cells to code (a smooth strip's last column of cells next to other content): the sixteen lanes of a quarter of the wave take one
+    // pixel each of one of those cells instead of 60 lanes watching four walk sixteen pixels; the per-tile reductions go through LDS atomics.
+    const int nValid = __popcll(validCells);
+    if (nValid <= 4) {
+        __shared__ uint8_t s_vl[4];
+        __shared__ int s_red[16][3];                                         // per tile: mode key, min, max of what is left
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(validCells >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)validCells, 0u));
+        if (valid) s_vl[rank] = (uint8_t)lane;
+        __syncthreads();
+        const int si = lane >> 4, k = lane & 15;
+        const bool act = si < nValid;
+        const int src = (int)s_vl[act ? si : 0];
+        const int sq = src >> 4, scx = src & 3, scy = (src >> 2) & 3, scxl = scx & 1, scyl = scy & 1;
+        const uint32_t cws = coverage[(size_t)SY * mtW + (BX * 4 + sq)];
+        const int sc00 = (scy & 2) * 4 + (scx & 2);
+        const int s00 = !((cws >> sc00) & 1), s10 = !((cws >> (sc00 + 1)) & 1), s01 = !((cws >> (sc00 + 4)) & 1), s11 = !((cws >> (sc00 + 5)) & 1);
+        const int snTop = s00 + s10, snBot = s01 + s11;
+        const int sposBase = scyl ? (16 * snTop + (scxl ? 4 * s01 : 0)) : (scxl ? 4 * s00 : 0), sposStep = 4 * (scyl ? snBot : snTop);
+        const int sgx = BX * 64 + sq * 16 + scx * 4, sgy = SY * 16 + scy * 4;          // the cell's origin
+        const size_t sti = (size_t)((sgy - scyl * 4) >> 3) * tilesW + ((sgx - scxl * 4) >> 3);
+        const int stw = sq * 4 + (scy >> 1) * 2 + (scx >> 1);
+        uint32_t* const shist = &s_hist[stw * 65];
+        const int32_t* planesS[3] = { pR, pG, pB };
+        for (int p = (onlyPlane < 0 ? 0 : onlyPlane); p < (onlyPlane < 0 ? 3 : onlyPlane + 1); p++) {
+            const int v = act ? (planesS[p][(size_t)(sgy + (k >> 2)) * strideElems + sgx + (k & 3)] & 255) : 0;      // CompressF(v,255) == v
+            __syncthreads();
+            // lane-contiguous 16-byte stores (a lane clearing its own 64-byte run put the whole wave on two LDS banks)
+            *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[256 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[512 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[768 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            if (lane < 4) *reinterpret_cast<uint4*>(&s_hist[1024 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            if (lane < 16) { s_red[lane][0] = -1; s_red[lane][1] = 99999; s_red[lane][2] = -99999; }
+            __syncthreads();
+            if (act) atomicAdd(&shist[v >> 2], 1u << (8 * (v & 3)));
+            __syncthreads();
+            if (act) atomicMax(&s_red[stw][0], (int)((((shist[v >> 2] >> (8 * (v & 3))) & 255u) << 8) | (uint32_t)v));   // right-most mode (:8335-8356)
+            __syncthreads();
+            int color0 = s_red[stw][0] & 255;
+            if (color0 == 0) color0 = 1;
+            if (color0 == 255) color0 = 254;
+            const bool isC0 = (v >= color0 - 1) && (v <= color0 + 1);
+            if (act && !isC0) { atomicMin(&s_red[stw][1], v); atomicMax(&s_red[stw][2], v); }                              // Model1 (:8358-8381)
+            __syncthreads();
+            const int mn = s_red[stw][1], mx = s_red[stw][2];
+            int minCol = 0, delta = 0;
+            if (mn != 99999) { minCol = mn; delta = mx - mn; }
+            if (act) {
+                int out = 0;
+                if (!isC0) {
+                    int idx = 0;
+                    if (delta) { const int n = (v - minCol) * 15 + (delta >> 1) - 1; idx = n < 0 ? -1 : yk_r1_div(n, delta); }      // GetValueModel1 (:8383-8391)
+                    out = 1 + idx;
+                }
+                slots[((size_t)p * T8 + sti) * 64 + sposBase + (k >> 2) * sposStep + (k & 3)] = (uint8_t)out;
+                if (k == 0) {                                                // every coded cell of a tile writes the same three parameters
+                    uint8_t* qp = params + ((size_t)p * T8 + sti) * 4;
+                    qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
+                }
+            }
+        }
+        return;
+    }
     const int tw = q * 4 + (cy >> 1) * 2 + (cx >> 1);                        // tile index inside the strip
     uint32_t* hist = &s_hist[tw * 65];
     // position of the lane's pixel rows among the tile's emitted pixels: top half rows (left then right quadrant), then bottom (:8420-8453)
@@ -73,10 +136,11 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             __syncthreads();                                                 // previous plane's readers are done (single wave: LDS fence)
 #pragma unroll
             for (int k = 0; k < 4; k++) s_px[(r0 + 4 * k) * 16 + (lane & 15)] = pk[k];
-            *reinterpret_cast<uint4*>(&s_hist[lane * 16]) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 4]) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 8]) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(&s_hist[lane * 16 + 12]) = make_uint4(0, 0, 0, 0);
+            // lane-contiguous 16-byte stores (a lane clearing its own 64-byte run put the whole wave on two LDS banks)
+            *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[256 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[512 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[768 + lane * 4]) = make_uint4(0, 0, 0, 0);
             if (lane < 4) *reinterpret_cast<uint4*>(&s_hist[1024 + lane * 4]) = make_uint4(0, 0, 0, 0);
             __syncthreads();
         }
