@@ -17,10 +17,14 @@ __device__ __forceinline__ int yk_r1_div(int n, int d) { return __float2int_rz((
 // lanes {l, l^1, l^4, l^5} (same geometry as yk_encode2_kernel).  Per plane: 256-byte row segments are loaded with 16-byte
 // loads and parked in LDS as bytes; the 256-bin histogram of a tile lives in 64 LDS words (4 byte-wide counters per word,
 // counts <= 64), filled with ds_add and read back per pixel; min / max / mode reductions are two xor-shuffles.
+// DIRECT: the stream offsets of every tile are known before the kernel runs (they depend on the coverage alone: yk_r1_offsets_kernel + one scan),
+// so pixel bytes and parameters go straight to their place in the reference's streams -- no per-tile slots, no compaction pass behind it.
+struct R1Direct { const uint32_t* offInBlk; const uint32_t* blockT; const uint32_t* blockP; const uint32_t* totals; uint8_t* pixOut; uint8_t* typeOut; };
+template <bool DIRECT>
 __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB,
                                                         int strideElems, int w, int h, const uint16_t* __restrict__ coverage, int mtW,
                                                         int tilesW, size_t T8, uint8_t* __restrict__ slots, uint8_t* __restrict__ params,
-                                                        uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix, int onlyPlane) {
+                                                        uint32_t* __restrict__ cntTiles, uint32_t* __restrict__ cntPix, int onlyPlane, const R1Direct D) {
     // onlyPlane < 0: the three planes share `coverage` (no partial-plane pass ran).  Otherwise this launch codes plane `onlyPlane` alone
     // against that plane's own coverage (mapSmoothTile->GetPlane(p), EncoderContext.cpp:9451-9465).
     __shared__ __attribute__((aligned(16))) uint32_t s_px[16 * 16];          // 16 rows x 64 pixels, one byte each
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     const int nPix = 16 * (nTop + nBot);
     const size_t ti = (size_t)(tgy >> 3) * tilesW + (tgx >> 3);
     const bool writer = tileIn && cxl == 0 && cyl == 0;
-    if (writer) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
+    if (!DIRECT && writer) { cntTiles[ti] = nPix ? 1u : 0u; cntPix[ti] = (uint32_t)nPix; }
     const unsigned long long validCells = __ballot(valid);                   // bit = lane = macroTile * 16 + cellY * 4 + cellX
     if (validCells == 0ULL) return;
     // ---- at most four cells to code (a smooth strip's last column of cells next to other content): the sixteen lanes of a quarter of the wave take one
@@ -102,10 +106,19 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
                     if (delta) { const int n = (v - minCol) * 15 + (delta >> 1) - 1; idx = n < 0 ? -1 : yk_r1_div(n, delta); }      // GetValueModel1 (:8383-8391)
                     out = 1 + idx;
                 }
-                slots[((size_t)p * T8 + sti) * 64 + sposBase + (k >> 2) * sposStep + (k & 3)] = (uint8_t)out;
-                if (k == 0) {                                                // every coded cell of a tile writes the same three parameters
-                    uint8_t* qp = params + ((size_t)p * T8 + sti) * 4;
-                    qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
+                if (DIRECT) {
+                    const uint32_t e = D.offInBlk[sti], blk = (uint32_t)(sti >> 10);
+                    D.pixOut[(size_t)p * D.totals[1] + D.blockP[blk] + (e >> 11) + sposBase + (k >> 2) * sposStep + (k & 3)] = (uint8_t)out;
+                    if (k == 0) {                                            // every coded cell of a tile writes the same three parameters
+                        uint8_t* qp = D.typeOut + ((size_t)p * D.totals[0] + D.blockT[blk] + (e & 2047u)) * 3;
+                        qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
+                    }
+                } else {
+                    slots[((size_t)p * T8 + sti) * 64 + sposBase + (k >> 2) * sposStep + (k & 3)] = (uint8_t)out;
+                    if (k == 0) {                                            // every coded cell of a tile writes the same three parameters
+                        uint8_t* qp = params + ((size_t)p * T8 + sti) * 4;
+                        qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
+                    }
                 }
             }
         }
@@ -184,7 +197,9 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
         int minCol = 0, delta = 0;
         if (mn != 99999) { minCol = mn; delta = mx - mn; }
         if (valid) {
-            uint8_t* slot = slots + ((size_t)p * T8 + ti) * 64;
+            uint8_t* slot;
+            if (DIRECT) { const uint32_t e = D.offInBlk[ti]; slot = D.pixOut + (size_t)p * D.totals[1] + D.blockP[ti >> 10] + (e >> 11); }
+            else slot = slots + ((size_t)p * T8 + ti) * 64;
             const int round = (delta >> 1) - 1;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -207,9 +222,49 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             }
         }
         if (writer && nPix) {
-            uint8_t* qp = params + ((size_t)p * T8 + ti) * 4;
+            uint8_t* qp;
+            if (DIRECT) qp = D.typeOut + ((size_t)p * D.totals[0] + D.blockT[ti >> 10] + (D.offInBlk[ti] & 2047u)) * 3;
+            else qp = params + ((size_t)p * T8 + ti) * 4;
             qp[0] = (uint8_t)color0; qp[1] = (uint8_t)minCol; qp[2] = (uint8_t)delta;
         }
+    }
+}
+
+// Stream offsets from the coverage alone (thread = tile, 1024 tiles per workgroup): a tile emits 16 bytes per uncovered quadrant and one
+// parameter triple when it emits anything.  Packed like the decoder's scan: coded tiles in the low 11 bits, pixel bytes above.
+__global__ __launch_bounds__(1024) void yk_r1_offsets_kernel(const uint16_t* __restrict__ coverage, int mtW, int tilesW, size_t T8,
+                                                             uint32_t* __restrict__ offInBlk, uint32_t* __restrict__ blockT, uint32_t* __restrict__ blockP) {
+    __shared__ uint32_t s_tmp[32];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t cnt = 0;
+    if (i < T8) {
+        const int tx = (int)(i % tilesW), ty = (int)(i / tilesW);
+        const uint32_t cw = coverage[(size_t)(ty >> 1) * mtW + (tx >> 1)];
+        const int c00 = (ty & 1) * 8 + (tx & 1) * 2;
+        const uint32_t n = 4u - (((cw >> c00) & 1u) + ((cw >> (c00 + 1)) & 1u) + ((cw >> (c00 + 4)) & 1u) + ((cw >> (c00 + 5)) & 1u));
+        cnt = (n ? 1u : 0u) | ((16u * n) << 11);
+    }
+    uint32_t tot;
+    const uint32_t e = yk_block_exscan(cnt, s_tmp, &tot);
+    if (i < T8) offInBlk[i] = e;
+    if (threadIdx.x == 0) { blockT[blockIdx.x] = tot & 2047u; blockP[blockIdx.x] = tot >> 11; }
+}
+// both block-sum arrays -> exclusive prefixes in place, totals[0] = coded tiles, totals[1] = pixel bytes of ONE plane
+__global__ __launch_bounds__(1024) void yk_r1_scan_kernel(uint32_t* __restrict__ blockT, uint32_t* __restrict__ blockP, int nBlocks, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tmp[32];
+#pragma unroll 1
+    for (int a = 0; a < 2; a++) {
+        uint32_t* arr = a ? blockP : blockT;
+        uint32_t base = 0;
+        for (int start = 0; start < nBlocks; start += 1024) {
+            const int i = start + threadIdx.x;
+            const uint32_t v = i < nBlocks ? arr[i] : 0u;
+            uint32_t tot;
+            const uint32_t e = yk_block_exscan(v, s_tmp, &tot);
+            if (i < nBlocks) arr[i] = base + e;
+            base += tot;
+        }
+        if (threadIdx.x == 0) totals[a] = base;
     }
 }
 
@@ -273,19 +328,18 @@ int yk_range1d_encode(yk_ctx* c) {
     const unsigned nStrips = (unsigned)(((c->fullW + 63) / 64) * ((c->h + 15) / 16));
     uint32_t t[2];
     if (!c->ppActive) {
-        { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
-        hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
-                           c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, -1);
-        { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
+        // three launches: offsets of every tile from the coverage, one scan, the coder writing straight into the streams (before: coder into
+        // per-tile slots, two block sums, two scans, a compaction pass re-reading the slots)
         { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
-        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
-        hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
-        hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bP, (int)nb, tot + 1);
-        hipLaunchKernelGGL(yk_range1d_pack_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, cT, cP, bT, bP, tot, T8, c->r1Slots, c->r1Params, c->r1Pix, c->r1Type,
-                           -1, (const uint32_t*)nullptr);
-        YK_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(yk_r1_offsets_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->coverage, c->mtW, c->tilesW, T8, cT, bT, bP);
+        hipLaunchKernelGGL(yk_r1_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
         { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
+        { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
+        R1Direct D; D.offInBlk = cT; D.blockT = bT; D.blockP = bP; D.totals = tot; D.pixOut = c->r1Pix; D.typeOut = c->r1Type;
+        hipLaunchKernelGGL(yk_range1d_kernel<true>, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                           c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, (uint8_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, -1, D);
+        YK_HIP(c, hipGetLastError());
+        { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
         // the totals stay on the device until a getter needs them (yk_range1d_finish): callers that keep frames in flight are not stopped here
         c->r1TotalsDev = tot; c->r1TotalsPending = true; c->r1Ready = true;
         return YK_OK;
@@ -294,8 +348,8 @@ int yk_range1d_encode(yk_ctx* c) {
         uint32_t* runBase = tot + 4;                                         // [4][2]: (tile-planes, pixel bytes) before plane p; [3] = totals
         YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
         for (int p = 0; p < 3; p++, runBase += 2) {
-            hipLaunchKernelGGL(yk_range1d_kernel, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
-                               c->fullW, c->h, c->covCh + (size_t)p * c->covChStride, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, p);
+            hipLaunchKernelGGL(yk_range1d_kernel<false>, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                               c->fullW, c->h, c->covCh + (size_t)p * c->covChStride, c->mtW, c->tilesW, T8, c->r1Slots, c->r1Params, cT, cP, p, R1Direct{});
             hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cT, T8, bT);
             hipLaunchKernelGGL(yk_u32_scanblocks_kernel, dim3(1), dim3(1024), 0, c->stream, bT, (int)nb, tot);
             hipLaunchKernelGGL(yk_u32_blocksum_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, cP, T8, bP);
