@@ -162,7 +162,7 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         kname, kms, note, bound = "yk_corner_* (lattice clear + owner + count + scan + emit, 7 passes)", per[0], "sparse scatter / gather: latency- and atomics-bound, far from the HBM roof by construction", "latency"
     elif args.stage == "range1d":
         pixn = uncovered * 3
-        alg = 12 * W * W + pixn + 64 * 0 + (W // 8) * (W // 8) * 3 * 3     # three int32 planes read once + 1 B per uncovered pixel and plane + 3 parameter bytes per tile-plane
+        alg = 12 * uncovered + pixn + (W // 8) * (W // 8) * 3 * 3          # the int32 samples of the uncovered 4x4 cells (all the coder fetches) + 1 B per uncovered pixel and plane written + 3 parameter bytes per tile-plane
         kname, kms, note, bound = "yk_range1d_kernel", per[1], f"tile offsets from the coverage + one scan (the coder writes straight into the streams): {per[2]:.4f} ms per frame on top", "hbm"
     elif args.stage == "lut3d":
         cand = int((~cov).sum()) * 16                         # pixels of tiles with anything left to code, an upper bound of what the passes read
