@@ -193,15 +193,32 @@ __global__ __launch_bounds__(256) void yk_decall_owner_kernel(const DecPlan pl, 
     const DPassGeo g = yk_dpass_geo(pl.sx[pass], pl.sy[pass], w);
     const DByteGeo b = yk_dbyte_geo(g, bi);
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
+    // tiles of the byte that lie inside the image (the reference skips the others, :58-60)
+    uint32_t live = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        if (!((byte >> k) & 1u)) continue;
         const uint32_t t = b.t0 + (uint32_t)k;
         const int x = b.bx0 + (int)((t & (uint32_t)b.tprMask) << g.sx), y = b.by0 + (int)((t >> b.tprShift) << g.sy);
-        if (x + (1 << g.sx) > w || y + (1 << g.sy) > h) continue;            // the reference skips tiles that leave the image (:58-60)
+        if (((byte >> k) & 1u) && !(x + (1 << g.sx) > w || y + (1 << g.sy) > h)) live |= 1u << k;
+    }
+    const bool two = g.tilesPerRow == 4;                                     // the byte is one row of 8 tiles, or two rows of 4
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (!((live >> k) & 1u)) continue;
+        const uint32_t t = b.t0 + (uint32_t)k;
+        const int x = b.bx0 + (int)((t & (uint32_t)b.tprMask) << g.sx), y = b.by0 + (int)((t >> b.tprShift) << g.sy);
         const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+        // a corner an EARLIER live tile of this same byte also touches belongs to that tile (smaller scan position): no atomic for it
+        // (left, upper, upper-left, upper-right neighbours; yk_corners.hip measured 32 -> 15 atomics for a dense group of 16x16 tiles)
+        const int col = (int)(t & (uint32_t)b.tprMask);
+        const bool left = k >= 1 && col != 0 && ((live >> (k - 1)) & 1u);
+        const bool up = two && k >= 4 && ((live >> (k - 4)) & 1u);
+        const bool upLeft = two && k >= 5 && col != 0 && ((live >> (k - 5)) & 1u);
+        const bool upRight = two && k >= 4 && col != 3 && ((live >> (k - 3)) & 1u);
+        const bool skip[4] = { left || up || upLeft, up || upRight, left, false };
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            if (skip[q]) continue;
             const size_t li = (size_t)((y >> 2) + ((q & 2) ? dy : 0)) * latW + (x >> 2) + ((q & 1) ? dx : 0);
             if (!(loaded[li] & 1)) atomicMin(&owner[li], key | (uint32_t)q);
         }
@@ -451,11 +468,13 @@ __device__ __forceinline__ uint32_t yk_d1_packed_count(int q) { return (q != 0xF
 
 // per block of 1024 tiles: coded tiles and pixel bytes, from the mask alone
 __global__ __launch_bounds__(1024) void yk_dec1d_count_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
-                                                              uint32_t* __restrict__ blockTiles, uint32_t* __restrict__ blockPix) {
+                                                              uint32_t* __restrict__ blockTiles, uint32_t* __restrict__ blockPix, uint32_t* __restrict__ offInBlk) {
     __shared__ uint32_t s_tmp[32];
     const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
     uint32_t tot;
-    yk_block_exscan(yk_d1_packed_count(yk_d1_quads(tile4, stride4, tilesW, T8, i)), s_tmp, &tot);
+    const int q = yk_d1_quads(tile4, stride4, tilesW, T8, i);
+    const uint32_t e = yk_block_exscan(yk_d1_packed_count(q), s_tmp, &tot);
+    if (i < T8) offInBlk[i] = e | ((uint32_t)q << 28);                         // the tile's packed offsets inside its block (28 bits) + its quadrant mask
     if (threadIdx.x == 0) { blockTiles[blockIdx.x] = tot & 2047u; blockPix[blockIdx.x] = tot >> 11; }
 }
 // both block-sum arrays -> exclusive prefixes in place, totals[0] = coded tiles, totals[1] = pixel bytes (one launch)
@@ -477,66 +496,63 @@ __global__ __launch_bounds__(1024) void yk_dec1d_scan_kernel(uint32_t* __restric
     }
 }
 
-// One workgroup = 1024 consecutive tiles of one plane.  Phase 1: one packed exclusive scan (thread = tile) gives every tile its offset in
-// the type and pixel streams.  Phase 2: FOUR lanes per tile, one lane per pair of rows of one half of the tile.  The stream holds a
-// half's rows as [left quadrant 4 B][right quadrant 4 B] per row, absent quadrants left out (:95-124): with both quadrants present a
-// row pair is 16 contiguous, 16-byte aligned stream bytes AND 16 contiguous bytes of the 8x8-tiled plane (one load, one store per
-// lane, a wave moves 1 KB per instruction); with one quadrant it is an 8-byte load and two 4-byte stores.
-__global__ __launch_bounds__(1024) void yk_dec1d_kernel(const uint8_t* __restrict__ tile4, int stride4, int tilesW, size_t T8,
-                                                        const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
-                                                        const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
-                                                        const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
-                                                        uint8_t* __restrict__ planes, size_t planeSize, int planeOverride, const uint32_t* __restrict__ runBase) {
-    __shared__ uint32_t s_tmp[32];
-    __shared__ uint32_t s_offT[1024], s_offP[1024];
-    __shared__ uint8_t s_q[1024];
+// FOUR lanes per tile, one lane per pair of rows of one half of the tile; a tile's offsets in the type and pixel streams come from the count
+// kernel's per-tile scan (offInBlk) + the scanned block sums, so the kernel is a plain stream: no workgroup scan, no barrier, every lane's loads
+// independent of every other lane's (the first form scanned 1024 tiles per workgroup of 1024 threads and then walked them in four rounds: two
+// resident workgroups per CU, each a chain of dependent round trips).  The stream holds a half's rows as [left quadrant 4 B][right quadrant
+// 4 B] per row, absent quadrants left out (:95-124): with both quadrants present a row pair is 16 contiguous, 16-byte aligned stream bytes AND
+// 16 contiguous bytes of the 8x8-tiled plane (one load, one store per lane, a wave moves 1 KB per instruction); with one quadrant it is an
+// 8-byte load and two 4-byte stores.
+__global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restrict__ offInBlk, size_t T8,
+                                                       const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
+                                                       const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
+                                                       const uint8_t* __restrict__ pix, size_t pixBytes, int invRange,
+                                                       uint8_t* __restrict__ planes, size_t planeSize, int planeOverride, const uint32_t* __restrict__ runBase) {
     // planeOverride < 0: the three planes share one mask (no partial-plane pass ran): plane = blockIdx.y, its streams start at
     // plane * totals.  Otherwise one plane per launch with its own mask, streams start at runBase (tiles, pixels of the planes before it).
     const int p = planeOverride < 0 ? (int)blockIdx.y : planeOverride;
     const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
-    const size_t i0 = (size_t)blockIdx.x * 1024;
-    {
-        const int q = yk_d1_quads(tile4, stride4, tilesW, T8, i0 + threadIdx.x);
-        uint32_t tot;
-        const uint32_t e = yk_block_exscan(yk_d1_packed_count(q), s_tmp, &tot);
-        s_offT[threadIdx.x] = baseTiles[blockIdx.x] + (e & 2047u); s_offP[threadIdx.x] = basePix[blockIdx.x] + (e >> 11); s_q[threadIdx.x] = (uint8_t)q;
-    }
-    __syncthreads();
     const int j = threadIdx.x & 3, half = j >> 1, rp = j & 1;
     uint8_t* const plane = planes + (size_t)p * planeSize;
-    // unrolled: the four tiles' loads are independent of each other's stores (restrict), so all of a lane's stream reads are in flight together
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int t = it * 256 + (threadIdx.x >> 2);
-        const size_t i = i0 + t;
-        if (i >= T8) break;
-        const int q = s_q[t];
+    {
+        const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+        if (i >= T8) return;
+        const uint32_t ow = offInBlk[i];
+        const int q = (int)(ow >> 28);
         const int qh = (q >> (half * 2)) & 3;                                    // bit 0: left quadrant filled, bit 1: right
-        if (qh == 3) continue;
+        if (qh == 3) return;
+        const uint32_t offT = baseTiles[i >> 10] + (ow & 2047u), offP = basePix[i >> 10] + ((ow >> 11) & 0x1FFFFu);
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
-        const size_t to = (baseT + s_offT[t]) * 3;
-        if (to + 2 >= typeBytes) continue;
+        const size_t to = (baseT + offT) * 3;
+        if (to + 2 >= typeBytes) return;
         const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
+        // v = L ? base + (((L - 1) * delta2) >> 16) : color0 (:113-124), four pixels of a dword at a time: for L >= 1 the value is byte 2 of
+        // K + L * delta2 with K = (base << 16) - delta2 (delta2 < 2^21, L a byte: a 24-bit multiply with the byte selected by the instruction);
+        // the bytes with L == 0 are found with the carry-free zero-byte mask and take color0.  4.5 operations per pixel instead of 8.
+        const uint32_t Kc = ((uint32_t)base << 16) - (uint32_t)delta2, d2u = (uint32_t)delta2, c0x4 = (uint32_t)color0 * 0x01010101u;
         auto dec4 = [&](uint32_t L4) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int L = (L4 >> (8 * k)) & 255;
-                const int v = L ? (base + (((L - 1) * delta2) >> 16)) : color0;     // :113-124
-                out |= (uint32_t)(v & 255) << (8 * k);
-            }
-            return out;
+            uint32_t t0, t1, t2, t3;
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(t0) : "v"(L4), "v"(d2u));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t1) : "v"(L4), "v"(d2u));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(t2) : "v"(L4), "v"(d2u));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(t3) : "v"(L4), "v"(d2u));
+            t0 += Kc; t1 += Kc; t2 += Kc; t3 += Kc;
+            const uint32_t lo = __builtin_amdgcn_perm(t1, t0, 0x0C0C0602u), hi = __builtin_amdgcn_perm(t3, t2, 0x06020C0Cu);   // byte 2 of each
+            const uint32_t dec = lo | hi;
+            const uint32_t z = ~(((L4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | L4 | 0x7F7F7F7Fu);                                       // 0x80 in every byte with L == 0
+            const uint32_t m = (z >> 7) * 255u;
+            return (dec & ~m) | (c0x4 & m);
         };
         uint8_t* const o = plane + i * 64 + (half * 4 + rp * 2) * 8;               // the lane's two rows: 16 contiguous bytes of the tile
         if (qh == 0) {
-            const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)rp * 16;
+            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 16;
             uint4 L = make_uint4(0u, 0u, 0u, 0u);
             if (po + 16 <= pixBytes) L = *reinterpret_cast<const uint4*>(pix + po);
             else if (po < pixBytes) { uint32_t tmp[4] = { 0, 0, 0, 0 }; for (int k = 0; k < 4; k++) if (po + 4 * k + 3 < pixBytes) tmp[k] = *reinterpret_cast<const uint32_t*>(pix + po + 4 * k); L = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]); }
             *reinterpret_cast<uint4*>(o) = make_uint4(dec4(L.x), dec4(L.y), dec4(L.z), dec4(L.w));
         } else {
-            const size_t po = baseP + s_offP[t] + (half ? 16 * nTop : 0) + (size_t)rp * 8;
+            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 8;
             uint2 L = make_uint2(0u, 0u);
             if (po + 8 <= pixBytes) L = *reinterpret_cast<const uint2*>(pix + po);
             else if (po + 3 < pixBytes) L.x = *reinterpret_cast<const uint32_t*>(pix + po);
@@ -830,8 +846,8 @@ static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBy
     const int w = c->dw, h = c->dh, tilesW = w >> 3;
     const size_t T8 = (size_t)tilesW * (h >> 3), nb = (T8 + 1023) / 1024;
     const size_t oTy = 0, oPx = (oTy + typeBytes + 31) & ~(size_t)15, oCT = (oPx + pixBytes + 31) & ~(size_t)15, oCP = oCT + 16,
-                 oBT = oCP + 16, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16;
-    int rc = yk_dec_scratch(c, oTot + 64); if (rc) return rc;
+                 oBT = oCP + 16, oBP = oBT + nb * 4 + 16, oTot = oBP + nb * 4 + 16, oOff = oTot + 64;
+    int rc = yk_dec_scratch(c, oOff + T8 * 4 + 64); if (rc) return rc;
     uint8_t* S = c->dScratch;
     // streams that already lie in HBM (16-byte aligned, as the encoder leaves them) are read where they are
     const bool inPlace = onDevice && ((reinterpret_cast<uintptr_t>(typeStream) | reinterpret_cast<uintptr_t>(pixStream)) & 15) == 0;
@@ -842,12 +858,14 @@ static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBy
     const uint8_t* const tyS = inPlace ? typeStream : S + oTy; const uint8_t* const pxS = inPlace ? pixStream : S + oPx;
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
+    uint32_t* offInBlk = reinterpret_cast<uint32_t*>(S + oOff);
+    const unsigned gTiles = (unsigned)((T8 + 63) / 64);
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     if (!c->dSplit) {
         // no partial-plane pass ran: the three planes share one mask, one count / scan serves all of them (3 launches)
-        hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP);
+        hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP, offInBlk);
         hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
-        hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 3), dim3(1024), 0, c->stream, c->dTile4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
+        hipLaunchKernelGGL(yk_dec1d_kernel, dim3(gTiles, 3), dim3(256), 0, c->stream, (const uint32_t*)offInBlk, T8, bT, bP, tot,
                            tyS, typeBytes, pxS, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, -1, (const uint32_t*)nullptr);
     } else {
         // per-plane masks (Decompress1D reads tile4x4Mask + planeID * tile4x4MaskSize, YAIK_3DTile.cpp:41): one plane after the other,
@@ -856,9 +874,9 @@ static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBy
         YK_HIP(c, hipMemsetAsync(runBase, 0, 2 * sizeof(uint32_t), c->stream));
         for (int p = 0; p < 3; p++) {
             const uint8_t* t4 = c->dTile4 + (size_t)p * c->dTile4Size;
-            hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP);
+            hipLaunchKernelGGL(yk_dec1d_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP, offInBlk);
             hipLaunchKernelGGL(yk_dec1d_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
-            hipLaunchKernelGGL(yk_dec1d_kernel, dim3((unsigned)nb, 1), dim3(1024), 0, c->stream, t4, (w + 15) >> 4, tilesW, T8, bT, bP, tot,
+            hipLaunchKernelGGL(yk_dec1d_kernel, dim3(gTiles, 1), dim3(256), 0, c->stream, (const uint32_t*)offInBlk, T8, bT, bP, tot,
                                tyS, typeBytes, pxS, pixBytes, (1 << 24) / compressionRange, c->dPlanes, c->dPlaneSize, p, (const uint32_t*)runBase);
             hipLaunchKernelGGL(yk_dec1d_next_plane_kernel, dim3(1), dim3(64), 0, c->stream, runBase, (const uint32_t*)tot);
         }
