@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 from oracle.refrun import have_ref, run_reference  # noqa: E402
 from tests.blobs import LUT_KEEP, PP_KEEP  # noqa: E402
-from tests.lutbank import bank16, bank_bytes, bank_patterns, lut_image, lut_image_rgba  # noqa: E402
+from tests.lutbank import bank16, bank_bytes, bank_patterns, lut_image, lut_image_rgba, random_bank  # noqa: E402
 from tests.images import edge_image, lineart_image, natural_photo, synth_planes  # noqa: E402
 
 PHOTO_SRC = "/opt/conda/lib/python3.9/site-packages/skimage/data/astronaut.png"       # present in the build image; never read by tests
@@ -50,6 +50,8 @@ LUT3D = {  # name -> (planes, patterns); `ref_driver ... lut3d <bank>` with the 
     "lut_lutmix128_rgb": lambda: (lut_image(128, 128, seed=3), bank_patterns()),
     "lut_lutmix192x144_rgb": lambda: (lut_image(192, 144, seed=7), bank_patterns()),
     "lut_lutmix256_rgba_bank16": lambda: (lut_image_rgba(256, 256, bank16(), seed=9), bank16()),     # 16 patterns, alpha plane in front
+    "lut_random_bank160x112_rgb": lambda: (lut_image(160, 112, random_bank(311, 9), seed=21), random_bank(311, 9)),   # unordered / duplicated / clustered points, partial 64x64 blocks
+    "lut_full_bank192x160_rgb": lambda: (lut_image(192, 160, random_bank(312, 64)[:8], seed=22), random_bank(312, 64)),   # a full bank: 64 patterns
 }
 # blobs that only serve debugging or are derivable from the others are dropped to keep the fixtures small
 DROP_PREFIX = ("preview_", "d1_out_", "mapSmoothTile_")
