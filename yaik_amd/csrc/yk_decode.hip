@@ -503,6 +503,9 @@ __global__ __launch_bounds__(1024) void yk_dec1d_scan_kernel(uint32_t* __restric
 // 4 B] per row, absent quadrants left out (:95-124): with both quadrants present a row pair is 16 contiguous, 16-byte aligned stream bytes AND
 // 16 contiguous bytes of the 8x8-tiled plane (one load, one store per lane, a wave moves 1 KB per instruction); with one quadrant it is an
 // 8-byte load and two 4-byte stores.
+#ifndef YK_D1_TPL
+#define YK_D1_TPL 4
+#endif
 __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restrict__ offInBlk, size_t T8,
                                                        const uint32_t* __restrict__ baseTiles, const uint32_t* __restrict__ basePix,
                                                        const uint32_t* __restrict__ totals /*[0]=tiles,[1]=pix*/, const uint8_t* __restrict__ type, size_t typeBytes,
@@ -514,17 +517,20 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
     const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
     const int j = threadIdx.x & 3, half = j >> 1, rp = j & 1;
     uint8_t* const plane = planes + (size_t)p * planeSize;
-    {
-        const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-        if (i >= T8) return;
+    // YK_D1_TPL tiles per lane (64 tiles apart, so that a wave's accesses stay contiguous): a wave that moves 1 KB lives about a microsecond and the
+    // launch is then bound by how fast waves can be started, not by the memory system
+#pragma unroll
+    for (int rep = 0; rep < YK_D1_TPL; rep++) {
+        const size_t i = ((size_t)blockIdx.x * YK_D1_TPL + rep) * 64 + (threadIdx.x >> 2);
+        if (i >= T8) continue;
         const uint32_t ow = offInBlk[i];
         const int q = (int)(ow >> 28);
         const int qh = (q >> (half * 2)) & 3;                                    // bit 0: left quadrant filled, bit 1: right
-        if (qh == 3) return;
+        if (qh == 3) continue;
         const uint32_t offT = baseTiles[i >> 10] + (ow & 2047u), offP = basePix[i >> 10] + ((ow >> 11) & 0x1FFFFu);
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
         const size_t to = (baseT + offT) * 3;
-        if (to + 2 >= typeBytes) return;
+        if (to + 2 >= typeBytes) continue;
         const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
         // v = L ? base + (((L - 1) * delta2) >> 16) : color0 (:113-124), four pixels of a dword at a time: for L >= 1 the value is byte 2 of
@@ -859,7 +865,7 @@ static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBy
     uint32_t* bT = reinterpret_cast<uint32_t*>(S + oBT); uint32_t* bP = reinterpret_cast<uint32_t*>(S + oBP);
     uint32_t* tot = reinterpret_cast<uint32_t*>(S + oTot);
     uint32_t* offInBlk = reinterpret_cast<uint32_t*>(S + oOff);
-    const unsigned gTiles = (unsigned)((T8 + 63) / 64);
+    const unsigned gTiles = (unsigned)((T8 + 64 * YK_D1_TPL - 1) / (64 * YK_D1_TPL));
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
     if (!c->dSplit) {
         // no partial-plane pass ran: the three planes share one mask, one count / scan serves all of them (3 launches)
