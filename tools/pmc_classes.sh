@@ -7,7 +7,7 @@ O=gpurun_out/r03/pmc_classes_$TAG.txt
 for v in "$@"; do
   export YK_LIB=$PWD/$v
   n=$(basename $v .so)
-  for cls in frame mild ramp noise; do
+  for cls in ${CLASSES:-frame mild ramp noise}; do
     timeout -k 10 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/r03/pmcc_${TAG}_${n}_$cls -- python3 tools/gpu_class_pmc.py $cls 0 > gpurun_out/r03/pmcc_${TAG}_${n}_$cls.log 2>&1 || exit 1
     python3 - "$TAG" "$n" "$cls" <<'PY' >> $O
 import csv, glob, collections, sys
