@@ -84,6 +84,12 @@ def test_c5_16384_rgba_stripes_and_decode_round_trip(hip):
     pix, typ = hip.dynamic_tile_compressor()
     dec.decompress_1d(typ, pix)
     tiled = dec.planes()
+    mask = dec.tile4x4()
+    # the same round trip without the host hop: the encoder's streams read where they lie in HBM, every gradient chunk in ONE call
+    # (yk_decode_gradient_all_device; 2^24 tile slots in the 4x4 pass here, just below the 2^25 its key holds)
+    dec.begin(W, W)
+    dec.decode_from_encoder(hip)
+    assert np.array_equal(dec.planes(), tiled) and np.array_equal(dec.tile4x4(), mask)
     dec.close()
     src = planes[:3].cpu().numpy()
     # 16x16 tiles the alpha reject keeps (any alpha != 0): the rejected ones are transparent and are not coded at all
