@@ -36,6 +36,36 @@ for seed in range(n0, n1):
         bad = compare_encode(planes, e, m3, want_dst=False, check_corners=True)
         if bad:
             bad_total += 1; print("MISMATCH encode seed", seed, "m3", m3, bad[:3], flush=True)
+    # (a') the live 1-D path behind the seven RGB passes (common coverage: offsets from the coverage, coder writing straight into the streams)
+    ora = OracleEncoder(planes)
+    if planes.shape[0] == 4:
+        ora.mip_prefilter()
+    for sx, sy in PASSES:
+        ora.fitting_quad_smooth(sx, sy)
+    for p in range(3):
+        ora.dynamic_tile_compressor(p)
+    pix, typ = ora.streams_1d()
+    e.set_image(planes)
+    if planes.shape[0] == 4:
+        e.mip_prefilter()
+    e.encode(3, False, False)
+    gp, gt = e.dynamic_tile_compressor()
+    if not (np.array_equal(gp, pix) and np.array_equal(gt, typ)):
+        bad_total += 1; print("MISMATCH 1-D seed", seed, flush=True)
+    # (a'') decode of that frame from the encoder's device-resident streams (all gradient chunks in one call) == pass-by-pass host-stream decode
+    hh, ww = planes.shape[1], planes.shape[2]
+    if hh % 16 == 0 and ww % 16 == 0:
+        d.begin(ww, hh)
+        cnts = e.gradient_counts()
+        for i, (sx, sy) in enumerate(PASSES):
+            if cnts[i]:
+                d.decompress_gradient(sx, sy, e.gradient_bitmap(i), palette_remap(e.gradient_corners(i), 250))
+        d.decompress_1d(gt, gp)
+        ref_planes, ref_mask = d.planes().copy(), d.tile4x4().copy()
+        d.begin(ww, hh)
+        d.decode_from_encoder(e)
+        if not (np.array_equal(d.planes(), ref_planes) and np.array_equal(d.tile4x4(), ref_mask)):
+            bad_total += 1; print("MISMATCH device-stream decode seed", seed, flush=True)
     # (b) plane-subset passes, random masks and shapes
     kind = ("planemix", "mixed", "photo")[seed % 3]
     img = edge_image(size + 16 * (seed % 2), size, kind, 3, seed=seed)
