@@ -526,12 +526,19 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
         const uint32_t ow = offInBlk[i];
         const int q = (int)(ow >> 28);
         const int qh = (q >> (half * 2)) & 3;                                    // bit 0: left quadrant filled, bit 1: right
-        if (qh == 3) continue;
-        const uint32_t offT = baseTiles[i >> 10] + (ow & 2047u), offP = basePix[i >> 10] + ((ow >> 11) & 0x1FFFFu);
+        // the 64 tiles of a workgroup's round lie in one scan block: its two bases are scalar loads
+        const size_t blk = (((size_t)blockIdx.x * YK_D1_TPL + rep) * 64) >> 10;
+        const uint32_t offT = baseTiles[blk] + (ow & 2047u), offP = basePix[blk] + ((ow >> 11) & 0x1FFFFu);
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
         const size_t to = (baseT + offT) * 3;
-        if (to + 2 >= typeBytes) continue;
-        const int color0 = type[to], base = type[to + 1], delta = type[to + 2];
+        // the tile's three parameter bytes: one byte load per lane (lane j of the tile fetches byte min(j, 2)), handed round the quad by DPP
+        // (three byte loads per lane were three of the kernel's eight memory instructions per tile, and those, not its bytes, bound it)
+        const bool tileCoded = q != 0xF && to + 2 < typeBytes;
+        int tb = 0;
+        if (tileCoded) tb = type[to + (j < 2 ? j : 2)];
+        const int color0 = __builtin_amdgcn_update_dpp(0, tb, 0x00, 0xF, 0xF, true), base = __builtin_amdgcn_update_dpp(0, tb, 0x55, 0xF, 0xF, true),
+                  delta = __builtin_amdgcn_update_dpp(0, tb, 0xAA, 0xF, 0xF, true);
+        if (qh == 3 || !tileCoded) continue;
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
         // v = L ? base + (((L - 1) * delta2) >> 16) : color0 (:113-124), four pixels of a dword at a time: for L >= 1 the value is byte 2 of
         // K + L * delta2 with K = (base << 16) - delta2 (delta2 < 2^21, L a byte: a 24-bit multiply with the byte selected by the instruction);
