@@ -517,28 +517,49 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
     const size_t baseT = planeOverride < 0 ? (size_t)p * totals[0] : (size_t)runBase[0], baseP = planeOverride < 0 ? (size_t)p * totals[1] : (size_t)runBase[1];
     const int j = threadIdx.x & 3, half = j >> 1, rp = j & 1;
     uint8_t* const plane = planes + (size_t)p * planeSize;
-    // YK_D1_TPL tiles per lane (64 tiles apart, so that a wave's accesses stay contiguous): a wave that moves 1 KB lives about a microsecond and the
-    // launch is then bound by how fast waves can be started, not by the memory system
+    // YK_D1_TPL tiles per lane, 64 tiles apart (a wave's accesses stay contiguous), in three phases so that a lane's round trips overlap instead of
+    // following each other: all offset words, then all parameter bytes and stream bytes, then the arithmetic and the stores.  (Tile after tile
+    // a wave made eight dependent round trips; with eight waves per SIMD and 48 waves per SIMD to run, those chains were the launch's duration.)
+    uint32_t ow[YK_D1_TPL];
 #pragma unroll
     for (int rep = 0; rep < YK_D1_TPL; rep++) {
         const size_t i = ((size_t)blockIdx.x * YK_D1_TPL + rep) * 64 + (threadIdx.x >> 2);
-        if (i >= T8) continue;
-        const uint32_t ow = offInBlk[i];
-        const int q = (int)(ow >> 28);
+        ow[rep] = i < T8 ? offInBlk[i] : 0xF0000000u;                           // past the end: a tile with nothing to decode
+    }
+    int tb[YK_D1_TPL]; uint4 L[YK_D1_TPL]; bool coded[YK_D1_TPL];
+#pragma unroll
+    for (int rep = 0; rep < YK_D1_TPL; rep++) {
+        const int q = (int)(ow[rep] >> 28);
         const int qh = (q >> (half * 2)) & 3;                                    // bit 0: left quadrant filled, bit 1: right
         // the 64 tiles of a workgroup's round lie in one scan block: its two bases are scalar loads
         const size_t blk = (((size_t)blockIdx.x * YK_D1_TPL + rep) * 64) >> 10;
-        const uint32_t offT = baseTiles[blk] + (ow & 2047u), offP = basePix[blk] + ((ow >> 11) & 0x1FFFFu);
+        const bool inRange = (((size_t)blockIdx.x * YK_D1_TPL + rep) * 64) < T8;
+        const uint32_t offT = (inRange ? baseTiles[blk] : 0u) + (ow[rep] & 2047u), offP = (inRange ? basePix[blk] : 0u) + ((ow[rep] >> 11) & 0x1FFFFu);
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
         const size_t to = (baseT + offT) * 3;
-        // the tile's three parameter bytes: one byte load per lane (lane j of the tile fetches byte min(j, 2)), handed round the quad by DPP
-        // (three byte loads per lane were three of the kernel's eight memory instructions per tile, and those, not its bytes, bound it)
-        const bool tileCoded = q != 0xF && to + 2 < typeBytes;
-        int tb = 0;
-        if (tileCoded) tb = type[to + (j < 2 ? j : 2)];
-        const int color0 = __builtin_amdgcn_update_dpp(0, tb, 0x00, 0xF, 0xF, true), base = __builtin_amdgcn_update_dpp(0, tb, 0x55, 0xF, 0xF, true),
-                  delta = __builtin_amdgcn_update_dpp(0, tb, 0xAA, 0xF, 0xF, true);
-        if (qh == 3 || !tileCoded) continue;
+        // the tile's three parameter bytes: one byte load per lane (lane j of the tile fetches byte min(j, 2)), handed round the quad by DPP below
+        coded[rep] = q != 0xF && to + 2 < typeBytes;
+        tb[rep] = 0;
+        if (coded[rep]) tb[rep] = type[to + (j < 2 ? j : 2)];
+        L[rep] = make_uint4(0u, 0u, 0u, 0u);
+        if (coded[rep] && qh == 0) {
+            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 16;
+            if (po + 16 <= pixBytes) L[rep] = *reinterpret_cast<const uint4*>(pix + po);
+            else if (po < pixBytes) { uint32_t tmp[4] = { 0, 0, 0, 0 }; for (int k = 0; k < 4; k++) if (po + 4 * k + 3 < pixBytes) tmp[k] = *reinterpret_cast<const uint32_t*>(pix + po + 4 * k); L[rep] = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]); }
+        } else if (coded[rep] && qh != 3) {
+            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 8;
+            if (po + 8 <= pixBytes) { const uint2 t2 = *reinterpret_cast<const uint2*>(pix + po); L[rep].x = t2.x; L[rep].y = t2.y; }
+            else if (po + 3 < pixBytes) L[rep].x = *reinterpret_cast<const uint32_t*>(pix + po);
+        }
+    }
+#pragma unroll
+    for (int rep = 0; rep < YK_D1_TPL; rep++) {
+        const size_t i = ((size_t)blockIdx.x * YK_D1_TPL + rep) * 64 + (threadIdx.x >> 2);
+        const int q = (int)(ow[rep] >> 28);
+        const int qh = (q >> (half * 2)) & 3;
+        const int color0 = __builtin_amdgcn_update_dpp(0, tb[rep], 0x00, 0xF, 0xF, true), base = __builtin_amdgcn_update_dpp(0, tb[rep], 0x55, 0xF, 0xF, true),
+                  delta = __builtin_amdgcn_update_dpp(0, tb[rep], 0xAA, 0xF, 0xF, true);
+        if (qh == 3 || !coded[rep]) continue;
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
         // v = L ? base + (((L - 1) * delta2) >> 16) : color0 (:113-124), four pixels of a dword at a time: for L >= 1 the value is byte 2 of
         // K + L * delta2 with K = (base << 16) - delta2 (delta2 < 2^21, L a byte: a 24-bit multiply with the byte selected by the instruction);
@@ -558,20 +579,11 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
             return (dec & ~m) | (c0x4 & m);
         };
         uint8_t* const o = plane + i * 64 + (half * 4 + rp * 2) * 8;               // the lane's two rows: 16 contiguous bytes of the tile
-        if (qh == 0) {
-            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 16;
-            uint4 L = make_uint4(0u, 0u, 0u, 0u);
-            if (po + 16 <= pixBytes) L = *reinterpret_cast<const uint4*>(pix + po);
-            else if (po < pixBytes) { uint32_t tmp[4] = { 0, 0, 0, 0 }; for (int k = 0; k < 4; k++) if (po + 4 * k + 3 < pixBytes) tmp[k] = *reinterpret_cast<const uint32_t*>(pix + po + 4 * k); L = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]); }
-            *reinterpret_cast<uint4*>(o) = make_uint4(dec4(L.x), dec4(L.y), dec4(L.z), dec4(L.w));
-        } else {
-            const size_t po = baseP + offP + (half ? 16 * nTop : 0) + (size_t)rp * 8;
-            uint2 L = make_uint2(0u, 0u);
-            if (po + 8 <= pixBytes) L = *reinterpret_cast<const uint2*>(pix + po);
-            else if (po + 3 < pixBytes) L.x = *reinterpret_cast<const uint32_t*>(pix + po);
+        if (qh == 0) *reinterpret_cast<uint4*>(o) = make_uint4(dec4(L[rep].x), dec4(L[rep].y), dec4(L[rep].z), dec4(L[rep].w));
+        else {
             const int side = qh & 1;                                             // left filled -> the present quadrant is the right one
-            *reinterpret_cast<uint32_t*>(o + side * 4) = dec4(L.x);
-            *reinterpret_cast<uint32_t*>(o + 8 + side * 4) = dec4(L.y);
+            *reinterpret_cast<uint32_t*>(o + side * 4) = dec4(L[rep].x);
+            *reinterpret_cast<uint32_t*>(o + 8 + side * 4) = dec4(L[rep].y);
         }
     }
 }
