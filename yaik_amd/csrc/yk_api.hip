@@ -141,6 +141,7 @@ int yk_create(int device, yk_ctx** out) {
     c->stream = c->ownStream;
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (hipEventCreate(&c->evRing[r][i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
     if (yk_qtab_get(c) != YK_OK) { yk_destroy(c); return YK_ERR_HIP; }
+    if (hipMalloc(&c->fusedQueue, 8 * 1088 * sizeof(uint32_t)) != hipSuccess) { yk_destroy(c); return YK_ERR_HIP; }
     *out = c;
     return YK_OK;
 }
@@ -153,7 +154,7 @@ void yk_destroy(yk_ctx* c) {
     yk_lut_destroy(c);
     yk_lut_dec_destroy(c);
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
+    F(c->fusedQueue); F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
     for (int st = 0; st < YK_NUM_STAGES; st++) for (int k = 0; k < YK_STAGE_RING; k++) for (int i = 0; i < 2; i++) if (c->stEv[st][k][i]) (void)hipEventDestroy(c->stEv[st][k][i]);
     if (c->frameGraph) (void)hipGraphExecDestroy(c->frameGraph);

@@ -44,6 +44,8 @@ struct YkEncodeParams {
     int xBB64, yBB64, xBB32, yBB32;
     int nFrames;            // 1 unless launched by yk_encode_batch
     const uint8_t* qtab;    // quantiser table of yk_encode2_kernel (yk_qtab_get)
+    uint32_t* queue;        // persistent grid: one strip counter per XCD, 64 bytes apart (cleared in front of the launch)
+    int qSlots;             // strip positions per XCD queue
     YkFrameStrides fs;
 };
 
@@ -51,6 +53,7 @@ struct yk_ctx {
     int device = -1;
     int numCU = 256;             // compute units of the device (persistent grids are sized from it)
     const uint8_t* qtab = nullptr;   // per-device quantiser table (owned by the library, shared by all handles)
+    uint32_t* fusedQueue = nullptr;  // the fused kernel's strip counters (8 XCDs x 64 bytes)
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;

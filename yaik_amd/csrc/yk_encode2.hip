@@ -493,6 +493,18 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, const uint32_t* deftab
 }
 
 #define YK2_RUN 16
+#define YK2_QSTRIDE 1088                                                 // words between the XCD queues' counters (4352 bytes: different L2 channels)
+#ifndef YK2_CHUNK
+#define YK2_CHUNK 4                                                      // persistent grid: strip positions a wave claims per atomic
+#endif
+// -DYK2_NOSTORE (timing experiments only, never shipped): every output store of the fused kernel feeds a checksum instead (the arithmetic stays)
+#ifdef YK2_NOSTORE
+#define Y2_STORE(lhs, val) do { y2sink ^= (uint32_t)(val); } while (0)
+#define Y2_ATOMIC(call, val) do { y2sink ^= (uint32_t)(val); } while (0)
+#else
+#define Y2_STORE(lhs, val) do { lhs = (val); } while (0)
+#define Y2_ATOMIC(call, val) do { call; } while (0)
+#endif
 // -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
 // five points, its entry time and its hardware slot (HW_ID, XCC_ID) into a device array that yk_debug_wave_times copies out.
 #ifdef YK2_TIMING
@@ -598,13 +610,23 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const unsigned long long y2_t_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned y2_hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), y2_xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
 #endif
+    // one 64x16 strip; `slot`, `xcd`: position in the XCD-aware unit order (below).  `lane` and the kernel arguments come in as parameters: the
+    // persistent loop hands over copies the optimiser cannot see through, so that nothing of a strip is kept in registers across strips
+    typedef const __attribute__((address_space(4))) YkEncodeParams* Y2ParamPtr;
+    auto strip = [&](const int slot, const int xcd, const bool loadRcp, const int lane, Y2ParamPtr const Pp, uint32_t& nextSlotS, const bool claimNext) {
+    const __attribute__((address_space(4))) YkEncodeParams& P = *Pp;
+    const int nBf = P.xBB64 * P.yBB64, nB = nBf * P.nFrames;             // blocks per frame / of the whole batch
+#ifdef YK2_PERSIST
+    uint32_t y2NextV = 0;
+#endif
+#ifdef YK2_NOSTORE
+    uint32_t y2sink = 0u;
+#endif
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
     // taken in row-major runs of YK2_RUN blocks (4 strips each); XCD k gets a rotating run of every group of 8 runs, so the
     // halo column of a block and the halo row of a strip are lines a neighbour streams through the same L2 at about the same
     // time instead of a second fabric fetch, while every XCD still samples the whole image (whole bands per XCD would leave
     // the cheapest band's XCD idle).
-    const int nBf = P.xBB64 * P.yBB64, nB = nBf * P.nFrames;             // blocks per frame / of the whole batch
-    const int slot = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
     const int grp = slot / (YK2_RUN * 4);
     const int unit = (grp * 8 + ((xcd + grp) & 7)) * (YK2_RUN * 4) + (slot - grp * (YK2_RUN * 4));
     int L = unit >> 2; const int wave = unit & 3;                            // block (row-major, frames back to back) and strip inside the block
@@ -670,7 +692,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         // the reciprocals of the range phase's error terms ride along (every strip pays one load and one LDS store; a coded strip used to
         // compute its 256 quotients itself, four correctly rounded divisions per lane)
-        const float4 rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
+        float4 rc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (loadRcp) rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
+#ifdef YK2_PERSIST
+        // the wave's next position in its XCD's queue: requested BEHIND the pixel loads (memory operations return in issue order: in front of
+        // them the counter's round trip would delay every pixel) and read after the strip
+        uint32_t nextSlotV = 0;
+        if (claimNext && lane == 0) nextSlotV = atomicAdd(&P.queue[xcd * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
+#endif
         __builtin_amdgcn_s_setprio(0);                                       // all loads are out
         uint4 o[4], ob;
 #pragma unroll
@@ -688,7 +717,10 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
         }
         if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
-        *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
+        if (loadRcp) *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
+#ifdef YK2_PERSIST
+        y2NextV = nextSlotV;
+#endif
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
@@ -764,11 +796,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
         }
     }
+#ifdef YK2_PERSIST
+    if (claimNext) nextSlotS = (uint32_t)__builtin_amdgcn_readfirstlane((int)y2NextV);   // arrived long ago (requested behind the pixel loads); a VGPR only until here
+#endif
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
     {   // coverage word of the macro-tile: bit = cellY*4 + cellX (row-major: Morton index with its two middle bits exchanged)
         const unsigned long long t = ((cov >> 2) ^ cov) & 0x0C0C0C0C0C0C0C0CULL;
         const unsigned long long covRM = cov ^ t ^ (t << 2);
-        if ((lane & 15) == 0 && mtIn) coverageP[mtIdx] = (uint16_t)((covRM >> (q * 16)) & 0xFFFFULL);
+        if ((lane & 15) == 0 && mtIn) Y2_STORE(coverageP[mtIdx], (uint16_t)((covRM >> (q * 16)) & 0xFFFFULL));
     }
 
     // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
@@ -778,20 +813,20 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     if (lane == 0) {
         const int i64 = BY * P.xBB64 + BX;
         const uint32_t nib = (s_bm[0] >> (4 * wave)) & 0xFu;
-        if (nib) atomicOr(reinterpret_cast<uint32_t*>(YK2_BM(0)) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave));
-        YK2_BM(1)[i64 * 4 + wave] = (uint8_t)(s_bm[1] >> (8 * wave));                                          // 16x8: tile rows 2w, 2w+1
-        YK2_BM(2)[i64 * 4 + wave] = (uint8_t)(s_bm[2] >> (8 * wave));                                          // 8x16: tile row w
-        reinterpret_cast<uint16_t*>(YK2_BM(3))[i64 * 4 + wave] = (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1)));   // 8x8: rows 2w, 2w+1
+        if (nib) Y2_ATOMIC(atomicOr(reinterpret_cast<uint32_t*>(YK2_BM(0)) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave)), nib);
+        Y2_STORE(YK2_BM(1)[i64 * 4 + wave], (uint8_t)(s_bm[1] >> (8 * wave)));                                         // 16x8: tile rows 2w, 2w+1
+        Y2_STORE(YK2_BM(2)[i64 * 4 + wave], (uint8_t)(s_bm[2] >> (8 * wave)));                                         // 8x16: tile row w
+        Y2_STORE(reinterpret_cast<uint16_t*>(YK2_BM(3))[i64 * 4 + wave], (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1))));   // 8x8: rows 2w, 2w+1
         {
             const int sb = wave >> 1;                                        // 8x4: 64x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-            if (BY * 2 + sb < P.yBB32) reinterpret_cast<uint32_t*>(YK2_BM(4))[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)] = s_bm[5 + sb * 2 + (wave & 1)];
+            if (BY * 2 + sb < P.yBB32) Y2_STORE(reinterpret_cast<uint32_t*>(YK2_BM(4))[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)], s_bm[5 + sb * 2 + (wave & 1)]);
         }
         for (int sx = 0; sx < 2; sx++) {
             if (BX * 2 + sx < P.xBB32) {
                 // 4x8: 32x64 swizzle blocks, tile rows 2w, 2w+1 = one u16;  4x4: 32x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-                reinterpret_cast<uint16_t*>(YK2_BM(5))[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave] = (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1)));
+                Y2_STORE(reinterpret_cast<uint16_t*>(YK2_BM(5))[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave], (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1))));
                 const int sy = wave >> 1;
-                if (BY * 2 + sy < P.yBB32) reinterpret_cast<uint32_t*>(YK2_BM(6))[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)] = s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)];
+                if (BY * 2 + sy < P.yBB32) Y2_STORE(reinterpret_cast<uint32_t*>(YK2_BM(6))[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)], s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)]);
             }
         }
     }
@@ -838,13 +873,13 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     if (bd != 0ULL && lane == 0) {
                         const int row = ((BY * 64 + wave * 16) >> 3) + r;
                         const size_t blk = ((size_t)row * P.tilesW + (size_t)BX * 8) >> 10;
-                        atomicAdd(&blockCntP[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
-                        atomicAdd(&blockCntP[blk * 2 + 1], (uint32_t)__popcll(bd));
+                        Y2_ATOMIC(atomicAdd(&blockCntP[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2))), __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
+                        Y2_ATOMIC(atomicAdd(&blockCntP[blk * 2 + 1], (uint32_t)__popcll(bd)), __popcll(bd));
                     }
                 }
             } else if (writer && n16 > 0) {
-                atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16);
-                atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2 + 1], 1u);
+                Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16), n16);
+                Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2 + 1], 1u), 1);
             }
         }
     }
@@ -854,7 +889,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     if (validMask == 0ULL || YK2_ABLATE(1)) {
         if (writer) {
 #pragma unroll
-            for (int p = 0; p < 3; p++) tileCountP[p * T8 + tileIdx] = 0;
+            for (int p = 0; p < 3; p++) Y2_STORE(tileCountP[p * T8 + tileIdx], 0);
         }
     } else {
         uint32_t* lut = &s_lut[WANT_DST ? tw : 0][0];
@@ -1209,7 +1244,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     // the store takes the scalar base + 32-bit offset form (hoisted 64-bit offsets cost 8 registers and a spill)
                     uint32_t so = slotOff[r];
                     asm volatile("" : "+v"(so));
-                    *reinterpret_cast<uint16_t*>(slotPlane + so) = (uint16_t)code16;
+                    Y2_STORE(*reinterpret_cast<uint16_t*>(slotPlane + so), (uint16_t)code16);
                     if (WANT_DST) {
                         const uint32_t* lb = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
                         int32_t* drow = P.dst[p] + (uint32_t)((gyCell + r) * w + gxCell);     // 32-bit element offset from a scalar base (w, h <= 32760)
@@ -1222,14 +1257,80 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 // scalar base + 32-bit lane offset, formed next to the stores (hoisted 64-bit addresses live across the planes and spill)
                 uint32_t ti = (uint32_t)tileIdx;
                 asm volatile("" : "+v"(ti));
-                (tileCountP + (size_t)p * T8)[ti] = (uint8_t)(tileLive ? 16 * (nTop + nBot) : 0);
+                Y2_STORE((tileCountP + (size_t)p * T8)[ti], (uint8_t)(tileLive ? 16 * (nTop + nBot) : 0));
                 // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
-                (tileDefP + (size_t)p * T8)[ti] = (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (tdef[p] >> 16));
+                Y2_STORE((tileDefP + (size_t)p * T8)[ti], (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (tdef[p] >> 16)));
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
     YK2_PROBE(4);
+#ifdef YK2_NOSTORE
+    if (y2sink == 0x9E3779B9u) P.coverage[lane] = 1;
+#endif
+    };   // strip
+#ifdef YK2_PERSIST
+    // Persistent waves: the grid is one wave per wave slot of the chip; a wave takes strips from its XCD's queue (a counter per XCD; the
+    // position in the queue is the `slot` of the one-shot grid, so the XCD-aware order is the same) and, when that runs dry, from the other
+    // XCDs' queues.  The next position is requested behind the strip's pixel loads and read after the strip: its round trip is never waited for.
+    {
+        Y2ParamPtr Pk = (Y2ParamPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = *reinterpret_cast<const float4*>(Pk->qtab + YK2_QBYTES + (size_t)lane * 16);
+        int qx = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7u), tried = 0;
+        const int nBk = Pk->xBB64 * Pk->yBB64 * Pk->nFrames;
+        // positions are claimed YK2_CHUNK at a time (one returning atomic per chunk: atomics on one address are served one after the other, about
+        // 90 per microsecond, and requests of other waves to the same L2 channel queue behind them)
+        uint32_t slot;
+        int left = YK2_CHUNK;                                             // positions of the current chunk not yet started
+        {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&Pk->queue[qx * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        }
+        for (;;) {
+            // the lane index and the kernel-argument pointer as values the optimiser cannot see through: nothing of a strip is hoisted out of the
+            // loop or kept in registers across strips (the lane index is recomputed, not kept: a register held across the loop would spill)
+            uint32_t ones = ~0u;
+            asm volatile("" : "+s"(ones), "+s"(Pk));
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+            const uint32_t nSlots = (uint32_t)Pk->qSlots;
+            for (;;) {
+                if (slot < nSlots) {                                      // positions beyond the image (the grid is padded to whole groups) are skipped
+                    const int grp = (int)slot / (YK2_RUN * 4);
+                    const int unit = (grp * 8 + ((qx + grp) & 7)) * (YK2_RUN * 4) + ((int)slot - grp * (YK2_RUN * 4));
+                    if ((unit >> 2) < nBk) break;
+                    if (--left > 0) { slot++; continue; }
+                } else {
+#ifdef YK2_STEAL
+                    // this queue is dry: look (plain loads) for another one that is not before claiming from it
+                    int k = 1;
+                    for (; k < 8; k++) {
+                        const uint32_t seen = __builtin_nontemporal_load(&Pk->queue[((qx + k) & 7) * YK2_QSTRIDE]);
+                        if (seen < nSlots) break;
+                    }
+                    if (k == 8 || ++tried == 16) return;
+                    qx = (qx + k) & 7;
+#else
+                    return;                                               // the queues are equally long and drain at the same rate: no stealing (a storm of claims on dry queues blocks their L2 channels)
+#endif
+                }
+                uint32_t t = 0;
+                if (ln == 0) t = atomicAdd(&Pk->queue[qx * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                left = YK2_CHUNK;
+            }
+            uint32_t nxtS = slot + 1;
+            left--;
+            strip((int)slot, qx, false, ln, Pk, nxtS, left == 0);
+            if (left == 0) left = YK2_CHUNK;
+            slot = nxtS;
+            __builtin_amdgcn_s_setprio(3);
+        }
+    }
+#else
+    uint32_t unusedNext = 0;
+    strip((int)blockIdx.x >> 3, (int)blockIdx.x & 7, true, lane, (Y2ParamPtr)__builtin_amdgcn_kernarg_segment_ptr(), unusedNext, false);
+#endif
 }
 
 // one set of tables per device and process, built on first use: quantiser rows | reciprocals | tile definitions
@@ -1269,7 +1370,17 @@ int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
     const int nB = P.xBB64 * P.yBB64 * P.nFrames, group = 8 * YK2_RUN;
     // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
     YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
+#ifdef YK2_PERSIST
+    YkEncodeParams Q = P;
+    Q.qSlots = ((nB + group - 1) / group) * group * 4 / 8;                  // positions per XCD queue
+    Q.queue = c->fusedQueue;
+    YK_HIP(c, hipMemsetAsync(c->fusedQueue, 0, 8 * YK2_QSTRIDE * sizeof(uint32_t), c->stream));
+    const int total = Q.qSlots * 8, resident = c->numCU * 16;
+    dim3 grid(total < resident ? total : resident);
+#define P Q
+#else
     dim3 grid(((nB + group - 1) / group) * group * 4);
+#endif
     if (P.wantDst) {
         if (P.startMode) hipLaunchKernelGGL((yk_encode2_kernel<true, true>), grid, dim3(64), 0, c->stream, P);
         else hipLaunchKernelGGL((yk_encode2_kernel<true, false>), grid, dim3(64), 0, c->stream, P);
@@ -1278,5 +1389,8 @@ int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
         else hipLaunchKernelGGL((yk_encode2_kernel<false, false>), grid, dim3(64), 0, c->stream, P);
     }
     YK_HIP(c, hipGetLastError());
+#ifdef YK2_PERSIST
+#undef P
+#endif
     return YK_OK;
 }
