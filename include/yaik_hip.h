@@ -346,6 +346,13 @@ enum { YK_STAGE_CORNERS = 0,       /* yk_gradient_corners: lattice clear + owner
        YK_STAGE_LUT3D = 6 };       /* yk_lut_search: yk_lut_search_kernel (one interval per tile shape) */
 int yk_stage_ms(yk_ctx* c, int stage, float* msSum, int* intervals);
 
+/* ---- diagnostics: the MEASURED HBM roof of this device (roofline fractions are quoted against the 8 TB/s specification
+ * AND against what the part really streams).  Two hand-written kernels with 16-byte accesses, eight loads per lane in flight, on a
+ * scratch pair of `bytes` each (allocated and freed inside the call; >= 1 MiB): *copyGBs = best of `reps` of dst[i] = src[i], read + write
+ * bytes counted (the figure MI355X_MICROARCH.md quotes: 6.29 TB/s); *readGBs = best of `reps` of a read-only stream.  Synchronises the
+ * handle's stream.  No part of the tile path. */
+int yk_measure_roof(yk_ctx* c, size_t bytes, int reps, double* copyGBs, double* readGBs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,7 @@ SIGNATURES = {
     "yk_decode_planes_device": (vp, [vp, szp]),
     "yk_gradient_corners_run": (C.c_int, [vp]),
     "yk_stage_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), ip]),
+    "yk_measure_roof": (C.c_int, [vp, sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "yk_decode_output": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_output_reference_rgba": (C.c_int, [vp, vp, sz, vp, C.c_int]),
     "yk_decode_tile4x4": (C.c_int, [vp, vp, sz]),

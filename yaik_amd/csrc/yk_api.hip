@@ -32,8 +32,10 @@ static void yk_free_image(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     auto& B = c->B;
     F(B.keep); F(B.bounds);
-    for (int i = 0; i < 7; i++) F(B.bitmap[i]);
-    F(B.coverage); F(B.tileDef); F(B.tileCount); F(B.slots);
+    F(B.small);                                                 // bitmaps, coverage, tile records, run sums: one allocation
+    for (int i = 0; i < 7; i++) B.bitmap[i] = nullptr;
+    B.coverage = nullptr; B.bm0b = nullptr; B.tileInfo = nullptr; B.runSums = nullptr;
+    F(B.tileDef); F(B.tileCount); F(B.slots);
     for (int i = 0; i < 3; i++) F(c->dst[i]);
     F(B.blockSums); F(B.blockCnt); F(B.totals); F(c->exportSizes); F(B.defsOut); F(B.nibOut);
     c->keep = nullptr; c->bounds = nullptr; for (int i = 0; i < 7; i++) c->bitmap[i] = nullptr;
@@ -55,16 +57,31 @@ static int yk_alloc_image(yk_ctx* c) {
     fs.keep = up(MT + 4, 16);                                   // read as 4-byte words by yk_alpha_bbox_kernel
     YK_HIP(c, hipMalloc(&B.keep, fs.keep * F + 16));
     YK_HIP(c, hipMalloc(&B.bounds, 16 * sizeof(int32_t) * F));
+    // The fused kernel's small outputs share ONE allocation (lanes holding different outputs then share a store instruction: scalar base + 32-bit
+    // lane offset, yk_encode2.hip): the seven bitmaps, the strips' 16x16 bytes, the coverage words, the per-tile records, the per-run sums;
+    // each array holds its nFrames copies back to back, 256-byte aligned.
     static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
+    size_t cur = 0, oBm[7], oBm0b, oCov, oInfo, oRun;
+    auto place = [&](size_t bytesPerFrame) { const size_t o = cur; cur = up(cur + bytesPerFrame * F + 16, 256); return o; };
     for (int i = 0; i < 7; i++) {
         const int bx = (sh[i][0] == 2) ? 32 : 64, by = (sh[i][1] == 2) ? 32 : 64;
         const size_t bits = (size_t)((c->fullW + bx - 1) / bx) * ((c->h + by - 1) / by) * ((bx >> sh[i][0]) * (by >> sh[i][1]));
         c->bitmapBytes[i] = bits >> 3;
         fs.bitmap[i] = up(c->bitmapBytes[i] + 4, 16);           // + the padding word pass 0 may touch
-        YK_HIP(c, hipMalloc(&B.bitmap[i], fs.bitmap[i] * F + 16));
+        oBm[i] = place(fs.bitmap[i]);
     }
-    fs.coverage = up(MT, 8); fs.tileDef = 3 * T8; fs.tileCount = 3 * T8; fs.slots = 3 * T8 * YK_SLOT;
-    YK_HIP(c, hipMalloc(&B.coverage, fs.coverage * F * sizeof(uint16_t)));
+    const size_t nB64 = (size_t)((c->fullW + 63) / 64) * ((c->h + 63) / 64);
+    fs.bm0b = up(nB64 * 4, 16); oBm0b = place(fs.bm0b);
+    fs.coverage = up(MT, 8); oCov = place(fs.coverage * sizeof(uint16_t));
+    fs.tileInfo = up(T8, 2); oInfo = place(fs.tileInfo * sizeof(uint2));
+    fs.runSums = up((T8 + 7) / 8, 4); oRun = place(fs.runSums * sizeof(uint32_t));
+    if (cur >= ((size_t)1 << 32)) return yk_fail(c, YK_ERR_BAD_ARG, "image too large for 32-bit offsets into the small-output arena");
+    YK_HIP(c, hipMalloc(&B.small, cur));
+    YK_HIP(c, hipMemset(B.small, 0, cur));                      // allocation time only
+    for (int i = 0; i < 7; i++) B.bitmap[i] = B.small + oBm[i];
+    B.bm0b = B.small + oBm0b; B.coverage = reinterpret_cast<uint16_t*>(B.small + oCov);
+    B.tileInfo = reinterpret_cast<uint2*>(B.small + oInfo); B.runSums = reinterpret_cast<uint32_t*>(B.small + oRun);
+    fs.tileDef = 3 * T8; fs.tileCount = 3 * T8; fs.slots = 3 * T8 * YK_SLOT;
     YK_HIP(c, hipMalloc(&B.tileDef, fs.tileDef * F * sizeof(uint16_t) + 16));
     YK_HIP(c, hipMalloc(&B.tileCount, fs.tileCount * F + 16));
     YK_HIP(c, hipMalloc(&B.slots, fs.slots * F + 16));
@@ -141,7 +158,6 @@ int yk_create(int device, yk_ctx** out) {
     c->stream = c->ownStream;
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (hipEventCreate(&c->evRing[r][i]) != hipSuccess) { delete c; return YK_ERR_HIP; }
     if (yk_qtab_get(c) != YK_OK) { yk_destroy(c); return YK_ERR_HIP; }
-    if (hipMalloc(&c->fusedQueue, 8 * 1088 * sizeof(uint32_t)) != hipSuccess) { yk_destroy(c); return YK_ERR_HIP; }
     *out = c;
     return YK_OK;
 }
@@ -154,7 +170,7 @@ void yk_destroy(yk_ctx* c) {
     yk_lut_destroy(c);
     yk_lut_dec_destroy(c);
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
-    F(c->fusedQueue); F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
+    F(c->ownedPlanes); F(c->dPlanes); F(c->dMapRGB); F(c->dLatticeOwner); F(c->dTile4); F(c->dScratch); F(c->dLoaded);
     for (int r = 0; r < YK_EV_RING; r++) for (int i = 0; i < 5; i++) if (c->evRing[r][i]) (void)hipEventDestroy(c->evRing[r][i]);
     for (int st = 0; st < YK_NUM_STAGES; st++) for (int k = 0; k < YK_STAGE_RING; k++) for (int i = 0; i < 2; i++) if (c->stEv[st][k][i]) (void)hipEventDestroy(c->stEv[st][k][i]);
     if (c->frameGraph) (void)hipGraphExecDestroy(c->frameGraph);
@@ -441,7 +457,8 @@ int yk_order_fused_after(yk_ctx* c, const yk_ctx* other) {
     YK_HIP(c, hipSetDevice(c->device));
     if (!c->auxStream) YK_HIP(c, hipStreamCreateWithFlags(&c->auxStream, hipStreamNonBlocking));
     if (!c->evFusedAfter) YK_HIP(c, hipEventCreateWithFlags(&c->evFusedAfter, hipEventDisableTiming));
-    YK_HIP(c, hipStreamWaitEvent(c->auxStream, other->evRing[(other->evHead - 1) % YK_EV_RING][3], 0));
+    static const int afterPack = getenv("YK_ORDER_AFTER_PACK") ? atoi(getenv("YK_ORDER_AFTER_PACK")) : 0;      // experiment switch
+    YK_HIP(c, hipStreamWaitEvent(c->auxStream, other->evRing[(other->evHead - 1) % YK_EV_RING][afterPack ? 4 : 3], 0));
     YK_HIP(c, hipEventRecord(c->evFusedAfter, c->auxStream));
     c->fusedAfter = c->evFusedAfter;
     return YK_OK;

@@ -18,6 +18,7 @@
 // the batch kernels address frame f at base + f * stride (elements of the array's own type).
 struct YkFrameStrides {
     unsigned long long plane, keep, bitmap[7], coverage, tileDef, tileCount, slots, blockN, defsOut, nibOut;   // bounds: 16 ints, totals: 8 u32
+    unsigned long long bm0b, tileInfo, runSums;   // the fused kernel's per-strip 16x16 bytes (u8), per-tile records (8 bytes each), run sums (u32)
 };
 
 struct YkEncodeParams {
@@ -44,8 +45,12 @@ struct YkEncodeParams {
     int xBB64, yBB64, xBB32, yBB32;
     int nFrames;            // 1 unless launched by yk_encode_batch
     const uint8_t* qtab;    // quantiser table of yk_encode2_kernel (yk_qtab_get)
-    uint32_t* queue;        // persistent grid: one strip counter per XCD, 64 bytes apart (cleared in front of the launch)
-    int qSlots;             // strip positions per XCD queue
+    // yk_encode2_kernel's small outputs live in ONE allocation, so that lanes holding different outputs can share a store instruction (scalar base
+    // + 32-bit lane offset): byte offsets, inside `small`, of frame 0 of the seven bitmaps (= bitmap[i]), of the strips' 16x16 bytes (4 bits each:
+    // yk_scan2_kernel folds them into bitmap[0]), the coverage words (= coverage), the per-tile records {def0 | def1 << 16, def2 | count << 16}
+    // and the per-run sums {nibbles / 16 | coded tiles << 16} (one per 8 consecutive tiles; widths that are multiples of 8 tiles only)
+    uint8_t* small;
+    uint32_t oBm[7], oBm0b, oCov, oInfo, oRun;
     YkFrameStrides fs;
 };
 
@@ -53,7 +58,6 @@ struct yk_ctx {
     int device = -1;
     int numCU = 256;             // compute units of the device (persistent grids are sized from it)
     const uint8_t* qtab = nullptr;   // per-device quantiser table (owned by the library, shared by all handles)
-    uint32_t* fusedQueue = nullptr;  // the fused kernel's strip counters (8 XCDs x 64 bytes)
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -66,6 +70,8 @@ struct yk_ctx {
     struct Bases {
         const int32_t* plane[4]; uint8_t* keep; int32_t* bounds; uint8_t* bitmap[7]; uint16_t* coverage; uint16_t* tileDef; uint8_t* tileCount;
         uint8_t* slots; uint32_t* blockSums; uint32_t* blockCnt; uint32_t* totals; uint16_t* defsOut; uint8_t* nibOut;
+        uint8_t* small;                 // one allocation: bitmap[0..6], bm0b, coverage, tileInfo, runSums (each nFrames times; the pointers above point into it)
+        uint8_t* bm0b; uint2* tileInfo; uint32_t* runSums;
     } B = {};
     // input
     const int32_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -493,18 +493,28 @@ __global__ void yk_selftest_qtab_kernel(const uint4* tab, const uint32_t* deftab
 }
 
 #define YK2_RUN 16
-#define YK2_QSTRIDE 1088                                                 // words between the XCD queues' counters (4352 bytes: different L2 channels)
-#ifndef YK2_CHUNK
-#define YK2_CHUNK 4                                                      // persistent grid: strip positions a wave claims per atomic
-#endif
-// -DYK2_NOSTORE (timing experiments only, never shipped): every output store of the fused kernel feeds a checksum instead (the arithmetic stays)
+// `old` with lane k replaced by the wave-uniform value `v` (v_writelane_b32 takes one scalar register: the lane is an inline constant; callers
+// pass constants or unrolled loop counters, so the switch folds away)
+template <int K> __device__ __forceinline__ uint32_t y2_writelane_k(uint32_t v, uint32_t old) { asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(K)); return old; }
+__device__ __forceinline__ uint32_t y2_writelane(uint32_t v, int k, uint32_t old) {
+    switch (k) {
+        case 0: return y2_writelane_k<0>(v, old); case 1: return y2_writelane_k<1>(v, old); case 2: return y2_writelane_k<2>(v, old);
+        case 3: return y2_writelane_k<3>(v, old); case 4: return y2_writelane_k<4>(v, old); default: return y2_writelane_k<5>(v, old);
+    }
+}
+__device__ __forceinline__ uint32_t y2_sinkable(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t y2_sinkable(uint2 v) { return v.x ^ v.y; }
+// -DYK2_NOSTORE=<bits> (timing experiments only, never shipped): output stores of the fused kernel feed a checksum instead (the arithmetic stays):
+// 1 = the nibble slots, 2 = per-tile counts and definitions, 4 = the atomics (16x16 map, scan sums), 8 = bitmaps, 16 = coverage
 #ifdef YK2_NOSTORE
-#define Y2_STORE(lhs, val) do { y2sink ^= (uint32_t)(val); } while (0)
-#define Y2_ATOMIC(call, val) do { y2sink ^= (uint32_t)(val); } while (0)
+#define Y2_SINK(val) do { y2sink ^= (uint32_t)(val); } while (0)
 #else
-#define Y2_STORE(lhs, val) do { lhs = (val); } while (0)
-#define Y2_ATOMIC(call, val) do { call; } while (0)
+#define YK2_NOSTORE 0
+#define Y2_SINK(val) do { } while (0)
 #endif
+#define Y2_STORE_IF(bit, lhs, val) do { if (YK2_NOSTORE & (bit)) Y2_SINK(y2_sinkable(val)); else lhs = (val); } while (0)
+#define Y2_STORE(lhs, val) Y2_STORE_IF(2, lhs, val)
+#define Y2_ATOMIC(call, val) do { if (YK2_NOSTORE & 4) Y2_SINK(val); else { call; } } while (0)
 // -DYK2_TIMING (tools/wave_timeline.sh only, never shipped): every wave records the shader clock and the 100 MHz real-time counter at
 // five points, its entry time and its hardware slot (HW_ID, XCC_ID) into a device array that yk_debug_wave_times copies out.
 #ifdef YK2_TIMING
@@ -610,16 +620,14 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const unsigned long long y2_t_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned y2_hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), y2_xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
 #endif
-    // one 64x16 strip; `slot`, `xcd`: position in the XCD-aware unit order (below).  `lane` and the kernel arguments come in as parameters: the
-    // persistent loop hands over copies the optimiser cannot see through, so that nothing of a strip is kept in registers across strips
+    // one 64x16 strip; `slot`, `xcd`: position in the XCD-aware unit order (below).  The kernel arguments are read through the kernel-argument
+    // segment pointer where they are used (scalar loads from the constant cache) instead of being copied into SGPRs at the top: 16 spilled
+    // SGPRs fewer.  (The lambda is what is left of the round-4 persistent-wave experiment, commit b2a2a39, profiles/r04/a*: DESIGN 5.3.)
     typedef const __attribute__((address_space(4))) YkEncodeParams* Y2ParamPtr;
-    auto strip = [&](const int slot, const int xcd, const bool loadRcp, const int lane, Y2ParamPtr const Pp, uint32_t& nextSlotS, const bool claimNext) {
+    auto strip = [&](const int slot, const int xcd, const int lane, Y2ParamPtr const Pp) {
     const __attribute__((address_space(4))) YkEncodeParams& P = *Pp;
     const int nBf = P.xBB64 * P.yBB64, nB = nBf * P.nFrames;             // blocks per frame / of the whole batch
-#ifdef YK2_PERSIST
-    uint32_t y2NextV = 0;
-#endif
-#ifdef YK2_NOSTORE
+#if YK2_NOSTORE
     uint32_t y2sink = 0u;
 #endif
     // XCD-aware unit order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  Units are
@@ -637,12 +645,8 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const int32_t* const pl0 = P.plane[0] + fr * P.fs.plane; const int32_t* const pl1 = P.plane[1] + fr * P.fs.plane; const int32_t* const pl2 = P.plane[2] + fr * P.fs.plane;
     const uint8_t* const keepP = P.keep ? P.keep + fr * P.fs.keep : nullptr;
     const int32_t* const boundsP = P.bounds ? P.bounds + fr * 16 : nullptr;
-    uint16_t* const coverageP = P.coverage + fr * P.fs.coverage;
-    uint16_t* const tileDefP = P.tileDef + fr * P.fs.tileDef;
-    uint8_t* const tileCountP = P.tileCount + fr * P.fs.tileCount;
     uint8_t* const slotsP = P.slots + fr * P.fs.slots;
     uint32_t* const blockCntP = P.blockCnt + fr * P.fs.blockN;
-#define YK2_BM(i) (P.bitmap[i] + fr * P.fs.bitmap[i])
     const int BY = L / P.xBB64, BX = L - BY * P.xBB64;
     const int w = P.w, h = P.h;
 
@@ -692,14 +696,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         // the reciprocals of the range phase's error terms ride along (every strip pays one load and one LDS store; a coded strip used to
         // compute its 256 quotients itself, four correctly rounded divisions per lane)
-        float4 rc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (loadRcp) rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
-#ifdef YK2_PERSIST
-        // the wave's next position in its XCD's queue: requested BEHIND the pixel loads (memory operations return in issue order: in front of
-        // them the counter's round trip would delay every pixel) and read after the strip
-        uint32_t nextSlotV = 0;
-        if (claimNext && lane == 0) nextSlotV = atomicAdd(&P.queue[xcd * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
-#endif
+        const float4 rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
         __builtin_amdgcn_s_setprio(0);                                       // all loads are out
         uint4 o[4], ob;
 #pragma unroll
@@ -717,10 +714,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             }
         }
         if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
-        if (loadRcp) *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
-#ifdef YK2_PERSIST
-        y2NextV = nextSlotV;
-#endif
+        *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
@@ -796,37 +790,57 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             for (int k = 0; k < 16; k++) pw[k] ^= 0x00808080u;
         }
     }
-#ifdef YK2_PERSIST
-    if (claimNext) nextSlotS = (uint32_t)__builtin_amdgcn_readfirstlane((int)y2NextV);   // arrived long ago (requested behind the pixel loads); a VGPR only until here
-#endif
     const int mtIdx = ((BY * 64 + wave * 16) >> 4) * P.mtW + ((BX * 64 + q * 16) >> 4);
-    {   // coverage word of the macro-tile: bit = cellY*4 + cellX (row-major: Morton index with its two middle bits exchanged)
-        const unsigned long long t = ((cov >> 2) ^ cov) & 0x0C0C0C0C0C0C0C0CULL;
-        const unsigned long long covRM = cov ^ t ^ (t << 2);
-        if ((lane & 15) == 0 && mtIn) Y2_STORE(coverageP[mtIdx], (uint16_t)((covRM >> (q * 16)) & 0xFFFFULL));
-    }
-
-    // ---- the strip's share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805).  Every pass packs the
-    // strip's tiles into whole bytes of the block's words except 16x16 (4 bits per strip), which is OR-ed into a pre-zeroed map.
+    // ---- the strip's small outputs: its share of the seven swizzled bitmaps (word index = swizzle-block index, :3801-3805; every pass packs the
+    // strip's tiles into whole bytes of the block's words except 16x16: 4 bits per strip, kept as a byte of their own that yk_scan2_kernel folds
+    // into the map), the coverage words of its four macro-tiles and, further down, the sums of its two runs of eight tiles and one 8-byte record
+    // per tile.  They all live in ONE allocation (P.small), so that lanes holding different outputs share a store instruction: the scalar base is
+    // common, the 32-bit byte offset is the lane's own.  Round 3 issued ~13 single-lane stores and up to five atomics per strip here (7 % of the
+    // kernel: profiles/r04/a6_*); now there is one store per access width and no atomic.
     __syncthreads();                                                         // fence: s_bm complete; s_pix dead, its LDS becomes s_lut
     YK2_PROBE(2);
-    if (lane == 0) {
-        const int i64 = BY * P.xBB64 + BX;
-        const uint32_t nib = (s_bm[0] >> (4 * wave)) & 0xFu;
-        if (nib) Y2_ATOMIC(atomicOr(reinterpret_cast<uint32_t*>(YK2_BM(0)) + (i64 >> 1), nib << ((i64 & 1) * 16 + 4 * wave)), nib);
-        Y2_STORE(YK2_BM(1)[i64 * 4 + wave], (uint8_t)(s_bm[1] >> (8 * wave)));                                         // 16x8: tile rows 2w, 2w+1
-        Y2_STORE(YK2_BM(2)[i64 * 4 + wave], (uint8_t)(s_bm[2] >> (8 * wave)));                                         // 8x16: tile row w
-        Y2_STORE(reinterpret_cast<uint16_t*>(YK2_BM(3))[i64 * 4 + wave], (uint16_t)(s_bm[3 + (wave >> 1)] >> (16 * (wave & 1))));   // 8x8: rows 2w, 2w+1
-        {
-            const int sb = wave >> 1;                                        // 8x4: 64x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-            if (BY * 2 + sb < P.yBB32) Y2_STORE(reinterpret_cast<uint32_t*>(YK2_BM(4))[((BY * 2 + sb) * P.xBB64 + BX) * 2 + (wave & 1)], s_bm[5 + sb * 2 + (wave & 1)]);
-        }
+    uint8_t* const small = P.small;
+    const uint32_t bmv = s_bm[lane < 24 ? lane : 0];                         // word k of the strip's bitmap image in lane k
+    auto bmWord = [&](const int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)bmv, k); };
+    const uint32_t i64 = (uint32_t)(BY * P.xBB64 + BX);
+    const uint32_t frU = (uint32_t)fr;
+    uint32_t off32 = ~0u, val32 = 0u;                                        // the 4-byte class is stored further down, with the run sums
+    {
+        const uint32_t w1 = (uint32_t)wave & 1u, w2 = (uint32_t)wave >> 1;
+        // bytes: lane 0 = 16x16 (4 bits), lane 1 = 16x8 (tile rows 2w, 2w+1), lane 2 = 8x16 (tile row w)
+        uint32_t off8 = 0u, val8 = 0u;
+        off8 = y2_writelane(P.oBm0b + frU * (uint32_t)P.fs.bm0b + i64 * 4u + (uint32_t)wave, 0, off8);
+        val8 = y2_writelane((bmWord(0) >> (4 * wave)) & 0xFu, 0, val8);
+        off8 = y2_writelane(P.oBm[1] + frU * (uint32_t)P.fs.bitmap[1] + i64 * 4u + (uint32_t)wave, 1, off8);
+        val8 = y2_writelane(bmWord(1) >> (8 * wave), 1, val8);
+        off8 = y2_writelane(P.oBm[2] + frU * (uint32_t)P.fs.bitmap[2] + i64 * 4u + (uint32_t)wave, 2, off8);
+        val8 = y2_writelane(bmWord(2) >> (8 * wave), 2, val8);
+        if (lane < 3) Y2_STORE_IF(8, *(small + off8), (uint8_t)val8);
+        // 16-bit words: lanes 0, 16, 32, 48 = coverage of the four macro-tiles (bit = cellY*4 + cellX: row-major, the Morton index with its two
+        // middle bits exchanged), lane 1 = 8x8 (tile rows 2w, 2w+1), lanes 2, 3 = 4x8 (32x64 swizzle blocks, tile rows 2w, 2w+1)
+        const unsigned long long t = ((cov >> 2) ^ cov) & 0x0C0C0C0C0C0C0C0CULL;
+        const unsigned long long covRM = cov ^ t ^ (t << 2);
+        uint32_t off16 = ((lane & 15) == 0 && mtIn) ? P.oCov + (frU * (uint32_t)P.fs.coverage + (uint32_t)mtIdx) * 2u : ~0u;
+        uint32_t val16 = (uint32_t)((covRM >> (q * 16)) & 0xFFFFULL);
+        off16 = y2_writelane(P.oBm[3] + frU * (uint32_t)P.fs.bitmap[3] + (i64 * 4u + (uint32_t)wave) * 2u, 1, off16);
+        val16 = y2_writelane(bmWord(3 + (int)w2) >> (16 * w1), 1, val16);
+#pragma unroll
         for (int sx = 0; sx < 2; sx++) {
-            if (BX * 2 + sx < P.xBB32) {
-                // 4x8: 32x64 swizzle blocks, tile rows 2w, 2w+1 = one u16;  4x4: 32x32 swizzle blocks, tile rows 4w..4w+3 = one dword
-                Y2_STORE(reinterpret_cast<uint16_t*>(YK2_BM(5))[(BY * P.xBB32 + BX * 2 + sx) * 4 + wave], (uint16_t)(s_bm[9 + sx * 2 + (wave >> 1)] >> (16 * (wave & 1))));
-                const int sy = wave >> 1;
-                if (BY * 2 + sy < P.yBB32) Y2_STORE(reinterpret_cast<uint32_t*>(YK2_BM(6))[((BY * 2 + sy) * P.xBB32 + BX * 2 + sx) * 2 + (wave & 1)], s_bm[13 + (sy * 2 + sx) * 2 + (wave & 1)]);
+            const bool in = BX * 2 + sx < P.xBB32;
+            off16 = y2_writelane(in ? P.oBm[5] + frU * (uint32_t)P.fs.bitmap[5] + ((uint32_t)((BY * P.xBB32 + BX * 2 + sx) * 4 + wave)) * 2u : ~0u, 2 + sx, off16);
+            val16 = y2_writelane(bmWord(9 + sx * 2 + (int)w2) >> (16 * w1), 2 + sx, val16);
+        }
+        if (off16 != ~0u) Y2_STORE_IF(8, *reinterpret_cast<uint16_t*>(small + off16), (uint16_t)val16);
+        // 32-bit words: lane 1 = 8x4 (64x32 swizzle blocks, tile rows 4w..4w+3), lanes 2, 3 = 4x4 (32x32 swizzle blocks); lanes 4, 5 = the run sums
+        {
+            const bool in = BY * 2 + (int)w2 < P.yBB32;
+            off32 = y2_writelane(in ? P.oBm[4] + frU * (uint32_t)P.fs.bitmap[4] + ((uint32_t)(((BY * 2 + (int)w2) * P.xBB64 + BX) * 2) + w1) * 4u : ~0u, 1, off32);
+            val32 = y2_writelane(bmWord(5 + (int)w2 * 2 + (int)w1), 1, val32);
+#pragma unroll
+            for (int sx = 0; sx < 2; sx++) {
+                const bool in6 = in && (BX * 2 + sx < P.xBB32);
+                off32 = y2_writelane(in6 ? P.oBm[6] + frU * (uint32_t)P.fs.bitmap[6] + ((uint32_t)(((BY * 2 + (int)w2) * P.xBB32 + BX * 2 + sx) * 2) + w1) * 4u : ~0u, 2 + sx, off32);
+                val32 = y2_writelane(bmWord(13 + ((int)w2 * 2 + sx) * 2 + (int)w1), 2 + sx, val32);
             }
         }
     }
@@ -857,40 +871,43 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     const int tw = lane >> 2;                                                // tile index inside the wave (0..15)
     const bool writer = ((lane & 3) == 0) && tileIn;                         // one lane per tile writes count / def
     const unsigned long long validMask = __ballot(valid);
+    // wave-uniform: every live tile has all four quadrants to code (then every lane of its quad is valid) -- the wide slot stores below
+#ifdef YK2_NO_WIDE_STORE
+    const bool fullTiles = false;
+#else
+    const bool fullTiles = !WANT_DST && __ballot(tileLive && quadN != 15u && quadN != 0u) == 0ULL;
+#endif
 
-    // ---- first level of the stream compaction's scan, fused: nibbles and coded tiles per block of 1024 tiles (row-major tile
-    // order = LeftRightOrder).  The counts are the same for the three planes.  A strip holds two runs of 8 consecutive tiles;
-    // when the tile grid is a multiple of 8 wide a run never straddles a scan block and one lane adds the run's sums.
+    // ---- first level of the stream compaction's scan, fused: nibbles and coded tiles per run of 8 consecutive tiles (row-major tile order =
+    // LeftRightOrder; the counts are the same for the three planes).  A strip holds two runs; when the tile grid is a multiple of 8 wide a run
+    // never straddles a scan block of 1024 tiles, and the strip stores each run's sums (nibbles / 16 | coded tiles << 16) in the run's own word:
+    // yk_scan2_kernel adds the 128 words of a block.  (Round 3 added them to the block's two counters with atomics: 128 strips of a tile row on
+    // one address, 15-23 % of the kernel on noisy frames.)  Other widths keep the atomics.
     {
         const int n16 = (tileLive && !YK2_ABLATE(1)) ? (nTop + nBot) : 0;   // nibbles / 16 of this tile-plane
-        if (__ballot(writer && n16 > 0) != 0ULL) {
-            if ((P.tilesW & 7) == 0) {
+        if ((P.tilesW & 7) == 0) {
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const bool mine = writer && ((cy >> 1) == r);
-                    const unsigned long long b0 = __ballot(mine && (n16 & 1)), b1 = __ballot(mine && (n16 & 2)), b2 = __ballot(mine && (n16 & 4));
-                    const unsigned long long bd = __ballot(mine && n16 > 0);
-                    if (bd != 0ULL && lane == 0) {
-                        const int row = ((BY * 64 + wave * 16) >> 3) + r;
-                        const size_t blk = ((size_t)row * P.tilesW + (size_t)BX * 8) >> 10;
-                        Y2_ATOMIC(atomicAdd(&blockCntP[blk * 2], 16u * (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2))), __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
-                        Y2_ATOMIC(atomicAdd(&blockCntP[blk * 2 + 1], (uint32_t)__popcll(bd)), __popcll(bd));
-                    }
-                }
-            } else if (writer && n16 > 0) {
-                Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16), n16);
-                Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2 + 1], 1u), 1);
+            for (int r = 0; r < 2; r++) {
+                const bool mine = writer && ((cy >> 1) == r);
+                const unsigned long long b0 = __ballot(mine && (n16 & 1)), b1 = __ballot(mine && (n16 & 2)), b2 = __ballot(mine && (n16 & 4));
+                const unsigned long long bd = __ballot(mine && n16 > 0);
+                const int row = ((BY * 64 + wave * 16) >> 3) + r;
+                off32 = y2_writelane(row < P.tilesH ? P.oRun + (frU * (uint32_t)P.fs.runSums + (uint32_t)(row * (P.tilesW >> 3) + BX)) * 4u : ~0u, 4 + r, off32);
+                val32 = y2_writelane((uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)) | ((uint32_t)__popcll(bd) << 16), 4 + r, val32);
             }
+        } else if (writer && n16 > 0) {
+            Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2], 16u * (uint32_t)n16), n16);
+            Y2_ATOMIC(atomicAdd(&blockCntP[((size_t)tileIdx >> 10) * 2 + 1], 1u), 1);
         }
+        if (off32 != ~0u) Y2_STORE_IF(8, *reinterpret_cast<uint32_t*>(small + off32), val32);
     }
 
     YK2_STAT(70, validMask != 0ULL ? 1 : 0); YK2_STAT(74, __popcll(validMask));
     { const int nv = __popcll(validMask); YK2_STAT(120 + (nv == 0 ? 0 : nv <= 4 ? 1 : nv <= 8 ? 2 : nv <= 16 ? 3 : nv <= 32 ? 4 : nv < 64 ? 5 : 6), 1); (void)nv; }
+    // one 8-byte record per tile: the three planes' definition words and the tile's nibble count (the same for the three planes), stored once
+    // behind the plane loop by the tile's first lane: 16 lanes x 8 bytes = two runs of 64 contiguous bytes per strip (round 3: six stores)
+    uint32_t defs01 = 0u, defs2c = 0u;
     if (validMask == 0ULL || YK2_ABLATE(1)) {
-        if (writer) {
-#pragma unroll
-            for (int p = 0; p < 3; p++) Y2_STORE(tileCountP[p * T8 + tileIdx], 0);
-        }
     } else {
         uint32_t* lut = &s_lut[WANT_DST ? tw : 0][0];
         // curve constants for buildLut (test-only reconstruction); fetched here, off the path of the strip's pixel loads
@@ -1235,7 +1252,21 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                 __builtin_amdgcn_wave_barrier();
             }
             // codes of the best mode, nibble-packed at the position of the lane's pixels among the tile's valid pixels (:1174-1190)
-            if (valid) {
+            if (valid && fullTiles) {
+                // every tile of the strip with anything to code is coded whole (no quadrant covered: noise, mild noise, most of a photograph): a tile
+                // row is [left cell's 4 nibbles | right cell's 4 nibbles], so the left cell's lane takes its neighbour's two words (DPP) and stores the
+                // 16 bytes of its half of the slot at once -- a wave then writes two runs of 256 contiguous bytes per plane instead of 256 scattered
+                // 2-byte pieces (the stores were 4.5 % of the frame's kernel time and 28 % of an all-noise frame's: profiles/r04/a2_*)
+                uint8_t* const slotPlane = slotsP + (size_t)p * T8 * YK_SLOT;
+                const uint32_t nLo = (uint32_t)y2_quad<Y2_QUAD_X>((int)cLo), nHi = (uint32_t)y2_quad<Y2_QUAD_X>((int)cHi);
+                if (cxl == 0) {
+                    uint32_t so = slotOff[0];
+                    asm volatile("" : "+v"(so));
+                    const uint4 half = make_uint4(__builtin_amdgcn_perm(nLo, cLo, 0x05040100u), __builtin_amdgcn_perm(nLo, cLo, 0x07060302u),
+                                                  __builtin_amdgcn_perm(nHi, cHi, 0x05040100u), __builtin_amdgcn_perm(nHi, cHi, 0x07060302u));
+                    if (YK2_NOSTORE & 1) Y2_SINK(half.x ^ half.y ^ half.z ^ half.w); else *reinterpret_cast<uint4*>(slotPlane + so) = half;
+                }
+            } else if (valid) {
                 uint8_t* const slotPlane = slotsP + (size_t)p * T8 * YK_SLOT;      // wave-uniform base + 32-bit lane offsets (3 * T8 * 32 < 2^32)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1244,7 +1275,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     // the store takes the scalar base + 32-bit offset form (hoisted 64-bit offsets cost 8 registers and a spill)
                     uint32_t so = slotOff[r];
                     asm volatile("" : "+v"(so));
-                    Y2_STORE(*reinterpret_cast<uint16_t*>(slotPlane + so), (uint16_t)code16);
+                    Y2_STORE_IF(1, *reinterpret_cast<uint16_t*>(slotPlane + so), (uint16_t)code16);
                     if (WANT_DST) {
                         const uint32_t* lb = lut + (bestMode < 3 ? bestMode * 20 : 60 + (bestMode - 3) * 8);
                         int32_t* drow = P.dst[p] + (uint32_t)((gyCell + r) * w + gxCell);     // 32-bit element offset from a scalar base (w, h <= 32760)
@@ -1253,84 +1284,25 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
                     }
                 }
             }
-            if (writer) {
-                // scalar base + 32-bit lane offset, formed next to the stores (hoisted 64-bit addresses live across the planes and spill)
-                uint32_t ti = (uint32_t)tileIdx;
-                asm volatile("" : "+v"(ti));
-                Y2_STORE((tileCountP + (size_t)p * T8)[ti], (uint8_t)(tileLive ? 16 * (nTop + nBot) : 0));
-                // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) stored as u16
-                Y2_STORE((tileDefP + (size_t)p * T8)[ti], (uint16_t)((((uint32_t)bestMode & 255u) << 13) | (tdef[p] >> 16)));
+            {
+                // TileInfo fields are u8 (:506-515); EncodeTileType(type,range,base) (include/YAIK_private.h:358) as u16
+                const uint32_t def16 = (((uint32_t)bestMode & 255u) << 13) | (tdef[p] >> 16);
+                if (p == 0) defs01 = def16 & 0xFFFFu; else if (p == 1) defs01 |= def16 << 16; else defs2c = def16 & 0xFFFFu;
             }
             __builtin_amdgcn_wave_barrier();
         }
+        defs2c |= (uint32_t)(tileLive ? 16 * (nTop + nBot) : 0) << 16;
+    }
+    if (writer) {
+        const uint32_t offI = P.oInfo + (frU * (uint32_t)P.fs.tileInfo + (uint32_t)tileIdx) * 8u;      // scalar base + 32-bit lane offset
+        Y2_STORE(*reinterpret_cast<uint2*>(small + offI), make_uint2(defs01, defs2c));
     }
     YK2_PROBE(4);
-#ifdef YK2_NOSTORE
+#if YK2_NOSTORE
     if (y2sink == 0x9E3779B9u) P.coverage[lane] = 1;
 #endif
     };   // strip
-#ifdef YK2_PERSIST
-    // Persistent waves: the grid is one wave per wave slot of the chip; a wave takes strips from its XCD's queue (a counter per XCD; the
-    // position in the queue is the `slot` of the one-shot grid, so the XCD-aware order is the same) and, when that runs dry, from the other
-    // XCDs' queues.  The next position is requested behind the strip's pixel loads and read after the strip: its round trip is never waited for.
-    {
-        Y2ParamPtr Pk = (Y2ParamPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = *reinterpret_cast<const float4*>(Pk->qtab + YK2_QBYTES + (size_t)lane * 16);
-        int qx = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7u), tried = 0;
-        const int nBk = Pk->xBB64 * Pk->yBB64 * Pk->nFrames;
-        // positions are claimed YK2_CHUNK at a time (one returning atomic per chunk: atomics on one address are served one after the other, about
-        // 90 per microsecond, and requests of other waves to the same L2 channel queue behind them)
-        uint32_t slot;
-        int left = YK2_CHUNK;                                             // positions of the current chunk not yet started
-        {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(&Pk->queue[qx * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
-            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        }
-        for (;;) {
-            // the lane index and the kernel-argument pointer as values the optimiser cannot see through: nothing of a strip is hoisted out of the
-            // loop or kept in registers across strips (the lane index is recomputed, not kept: a register held across the loop would spill)
-            uint32_t ones = ~0u;
-            asm volatile("" : "+s"(ones), "+s"(Pk));
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
-            const uint32_t nSlots = (uint32_t)Pk->qSlots;
-            for (;;) {
-                if (slot < nSlots) {                                      // positions beyond the image (the grid is padded to whole groups) are skipped
-                    const int grp = (int)slot / (YK2_RUN * 4);
-                    const int unit = (grp * 8 + ((qx + grp) & 7)) * (YK2_RUN * 4) + ((int)slot - grp * (YK2_RUN * 4));
-                    if ((unit >> 2) < nBk) break;
-                    if (--left > 0) { slot++; continue; }
-                } else {
-#ifdef YK2_STEAL
-                    // this queue is dry: look (plain loads) for another one that is not before claiming from it
-                    int k = 1;
-                    for (; k < 8; k++) {
-                        const uint32_t seen = __builtin_nontemporal_load(&Pk->queue[((qx + k) & 7) * YK2_QSTRIDE]);
-                        if (seen < nSlots) break;
-                    }
-                    if (k == 8 || ++tried == 16) return;
-                    qx = (qx + k) & 7;
-#else
-                    return;                                               // the queues are equally long and drain at the same rate: no stealing (a storm of claims on dry queues blocks their L2 channels)
-#endif
-                }
-                uint32_t t = 0;
-                if (ln == 0) t = atomicAdd(&Pk->queue[qx * YK2_QSTRIDE], (uint32_t)YK2_CHUNK);
-                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                left = YK2_CHUNK;
-            }
-            uint32_t nxtS = slot + 1;
-            left--;
-            strip((int)slot, qx, false, ln, Pk, nxtS, left == 0);
-            if (left == 0) left = YK2_CHUNK;
-            slot = nxtS;
-            __builtin_amdgcn_s_setprio(3);
-        }
-    }
-#else
-    uint32_t unusedNext = 0;
-    strip((int)blockIdx.x >> 3, (int)blockIdx.x & 7, true, lane, (Y2ParamPtr)__builtin_amdgcn_kernarg_segment_ptr(), unusedNext, false);
-#endif
+    strip((int)blockIdx.x >> 3, (int)blockIdx.x & 7, lane, (Y2ParamPtr)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // one set of tables per device and process, built on first use: quantiser rows | reciprocals | tile definitions
@@ -1368,19 +1340,8 @@ int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
     if (!P.qtab) return yk_fail(c, YK_ERR_STATE, "quantiser table missing");
     if (P.startMode != 0 && P.startMode != 3) return yk_fail(c, YK_ERR_BAD_ARG, "startMode must be 0 or 3");
     const int nB = P.xBB64 * P.yBB64 * P.nFrames, group = 8 * YK2_RUN;
-    // 16x16 map: strips OR their 4 bits in (a batch clears the maps of all frames, padding included)
-    YK_HIP(c, hipMemsetAsync(P.bitmap[0], 0, P.nFrames > 1 ? (size_t)P.fs.bitmap[0] * P.nFrames : (((size_t)nB * 2 + 3) & ~(size_t)3), c->stream));
-#ifdef YK2_PERSIST
-    YkEncodeParams Q = P;
-    Q.qSlots = ((nB + group - 1) / group) * group * 4 / 8;                  // positions per XCD queue
-    Q.queue = c->fusedQueue;
-    YK_HIP(c, hipMemsetAsync(c->fusedQueue, 0, 8 * YK2_QSTRIDE * sizeof(uint32_t), c->stream));
-    const int total = Q.qSlots * 8, resident = c->numCU * 16;
-    dim3 grid(total < resident ? total : resident);
-#define P Q
-#else
+    // (the 16x16 map needs no clearing any more: the strips store their 4 bits as bytes of their own, yk_scan2_kernel folds them into the map)
     dim3 grid(((nB + group - 1) / group) * group * 4);
-#endif
     if (P.wantDst) {
         if (P.startMode) hipLaunchKernelGGL((yk_encode2_kernel<true, true>), grid, dim3(64), 0, c->stream, P);
         else hipLaunchKernelGGL((yk_encode2_kernel<true, false>), grid, dim3(64), 0, c->stream, P);
@@ -1389,8 +1350,5 @@ int yk_launch_encode2(yk_ctx* c, const YkEncodeParams& P) {
         else hipLaunchKernelGGL((yk_encode2_kernel<false, false>), grid, dim3(64), 0, c->stream, P);
     }
     YK_HIP(c, hipGetLastError());
-#ifdef YK2_PERSIST
-#undef P
-#endif
     return YK_OK;
 }

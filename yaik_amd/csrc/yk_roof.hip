@@ -9,18 +9,19 @@
 // against it; bench.py therefore takes the better of these two kernels as `peak_measured`.
 #include "yk_common.h"
 
+typedef uint32_t yk_v4u __attribute__((ext_vector_type(4)));
 #define YK_ROOF_THREADS 256
 #define YK_ROOF_UNROLL 8
 
-__global__ __launch_bounds__(YK_ROOF_THREADS) void yk_roof_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+__global__ __launch_bounds__(YK_ROOF_THREADS) void yk_roof_copy_kernel(const yk_v4u* __restrict__ src, yk_v4u* __restrict__ dst, size_t n16) {
     // a workgroup moves contiguous chunks of UNROLL x 4 KB; every lane has UNROLL loads in flight before its first store
     const size_t chunk = (size_t)YK_ROOF_THREADS * YK_ROOF_UNROLL;
     for (size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk) {
-        uint4 v[YK_ROOF_UNROLL];
+        yk_v4u v[YK_ROOF_UNROLL];
 #pragma unroll
         for (int k = 0; k < YK_ROOF_UNROLL; k++) {
             const size_t i = base + (size_t)k * YK_ROOF_THREADS + threadIdx.x;
-            v[k] = i < n16 ? __builtin_nontemporal_load(&src[i]) : make_uint4(0u, 0u, 0u, 0u);
+            v[k] = i < n16 ? __builtin_nontemporal_load(&src[i]) : (yk_v4u){0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < YK_ROOF_UNROLL; k++) {
@@ -30,15 +31,15 @@ __global__ __launch_bounds__(YK_ROOF_THREADS) void yk_roof_copy_kernel(const uin
     }
 }
 
-__global__ __launch_bounds__(YK_ROOF_THREADS) void yk_roof_read_kernel(const uint4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+__global__ __launch_bounds__(YK_ROOF_THREADS) void yk_roof_read_kernel(const yk_v4u* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
     const size_t chunk = (size_t)YK_ROOF_THREADS * YK_ROOF_UNROLL;
     uint32_t acc = 0u;
     for (size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk) {
-        uint4 v[YK_ROOF_UNROLL];
+        yk_v4u v[YK_ROOF_UNROLL];
 #pragma unroll
         for (int k = 0; k < YK_ROOF_UNROLL; k++) {
             const size_t i = base + (size_t)k * YK_ROOF_THREADS + threadIdx.x;
-            v[k] = i < n16 ? __builtin_nontemporal_load(&src[i]) : make_uint4(0u, 0u, 0u, 0u);
+            v[k] = i < n16 ? __builtin_nontemporal_load(&src[i]) : (yk_v4u){0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < YK_ROOF_UNROLL; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
@@ -51,7 +52,7 @@ extern "C" int yk_measure_roof(yk_ctx* c, size_t bytes, int reps, double* copyGB
     if (!c || bytes < (1u << 20) || reps < 1 || reps > 100) return c ? yk_fail(c, YK_ERR_BAD_ARG, "yk_measure_roof arguments") : YK_ERR_BAD_ARG;
     YK_HIP(c, hipSetDevice(c->device));
     bytes &= ~(size_t)4095;
-    uint4* a = nullptr; uint4* b = nullptr; uint32_t* sink = nullptr;
+    yk_v4u* a = nullptr; yk_v4u* b = nullptr; uint32_t* sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = YK_OK;
     const size_t n16 = bytes / 16;

@@ -119,12 +119,8 @@ __global__ __launch_bounds__(1024) void yk_scan1_kernel(const uint8_t* __restric
 }
 
 // second level: exclusive prefix over the per-block sums (consumed and cleared for the next frame) and the totals of the
-// three planes (identical: the counts do not depend on the plane).
-__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
-                                                        uint32_t* __restrict__ totals, unsigned long long blockNStride) {
-    __shared__ uint32_t s_tmp[32];
-    blockCnt += (size_t)blockIdx.x * blockNStride; blockSums += (size_t)blockIdx.x * blockNStride;     // blockIdx.x = frame of a batch
-    totals += (size_t)blockIdx.x * 8;
+// three planes (identical: the counts do not depend on the plane).  One workgroup of 1024 threads.
+__device__ __forceinline__ void yk_scan2_body(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks, uint32_t* __restrict__ totals, uint32_t* s_tmp) {
     uint32_t baseN = 0, baseD = 0;
     for (int start = 0; start < nBlocks; start += 1024) {
         const int i = start + threadIdx.x;
@@ -140,43 +136,111 @@ __global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ b
     }
     if (threadIdx.x < 3) { totals[threadIdx.x * 2] = baseD; totals[threadIdx.x * 2 + 1] = baseN; }
 }
-
-// One workgroup packs the nibbles of 1024 consecutive tiles.  Every tile holds a multiple of 16 nibbles (16 per uncovered 4x4
-// quadrant), so every stream offset is a multiple of 8 bytes: after the scan, four lanes per tile copy 8-byte pieces of the
-// tile's slot straight to its place in the stream, reading only the bytes that exist.
-__global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef,
-                                                       const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
-                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords, YkFrameStrides fs) {
+__global__ __launch_bounds__(1024) void yk_scan2_kernel(uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ blockSums, int nBlocks,
+                                                        uint32_t* __restrict__ totals, unsigned long long blockNStride) {
     __shared__ uint32_t s_tmp[32];
+    yk_scan2_body(blockCnt + (size_t)blockIdx.x * blockNStride, blockSums + (size_t)blockIdx.x * blockNStride, nBlocks, totals + (size_t)blockIdx.x * 8, s_tmp);   // blockIdx.x = frame of a batch
+}
+
+// first level for the second-generation fused kernel, which neither adds to shared counters nor ORs into a shared map (atomics on one address are
+// served one after the other and were 15-23 % of that kernel on noisy frames): every strip leaves the sums of its two runs of eight tiles in words
+// of their own (runSums: nibbles / 16 | coded tiles << 16) and its four 16x16 bits in a byte of its own (bm0b).  Here the 128 run words of a scan
+// block = 32 consecutive 16-byte pieces = one half-wave are added into the block's two counters (plain stores: nothing to clear, every word is
+// rewritten every frame), and the four bytes of a 64x64 block are folded into its 16-bit word of the 16x16 map.
+__global__ __launch_bounds__(1024) void yk_scan1r_kernel(const uint32_t* __restrict__ runSums, unsigned long long runStride, int nRuns,
+                                                         uint32_t* __restrict__ blockCnt, unsigned long long blockNStride, int nBlocks,
+                                                         const uint8_t* __restrict__ bm0b, unsigned long long bm0bStride, uint8_t* __restrict__ bitmap0,
+                                                         unsigned long long bitmap0Stride, int nB64) {
+    const size_t f = blockIdx.y;                                                  // frame of a batch
+    const int g = (int)blockIdx.x * 1024 + (int)threadIdx.x;
+    if (runSums) {
+        const uint4* rs4 = reinterpret_cast<const uint4*>(runSums + f * runStride);
+        const int n4 = (nRuns + 3) >> 2;                                          // the array is padded with zero words to a multiple of four
+        const uint4 v = g < n4 ? rs4[g] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t acc = v.x + v.y + v.z + v.w;                                     // both 16-bit halves at once: at most 128 x 32 and 128 x 8 per block
+        acc += __shfl_xor(acc, 16, 32); acc += __shfl_xor(acc, 8, 32); acc += __shfl_xor(acc, 4, 32); acc += __shfl_xor(acc, 2, 32); acc += __shfl_xor(acc, 1, 32);
+        const int blk = g >> 5;
+        if ((threadIdx.x & 31) == 0 && blk < nBlocks) {
+            uint2* dst = reinterpret_cast<uint2*>(blockCnt + f * blockNStride) + blk;
+            *dst = make_uint2(16u * (acc & 0xFFFFu), acc >> 16);
+        }
+    }
+    if (g < nB64) {
+        const uint32_t b = reinterpret_cast<const uint32_t*>(bm0b + f * bm0bStride)[g];   // the four strips' bytes of block g, 4 bits each
+        uint16_t* dst = reinterpret_cast<uint16_t*>(bitmap0 + f * bitmap0Stride);
+        dst[g] = (uint16_t)((b & 0xFu) | ((b >> 4) & 0xF0u) | ((b >> 8) & 0xF00u) | ((b >> 12) & 0xF000u));
+        if (g == nB64 - 1 && (nB64 & 1)) dst[nB64] = 0;                           // the padding half of the last 32-bit word (word-wise consumers)
+    }
+}
+
+// One workgroup packs the nibbles of 1024 consecutive tiles, the three planes one after the other: a tile's count is the same in the three
+// planes, so ONE scan serves them all (round 3 ran a workgroup and two block scans per plane).  Every tile holds a multiple of 16 nibbles
+// (16 per uncovered 4x4 quadrant), so every stream offset is a multiple of 8 bytes: after the scan, four lanes per tile copy 8-byte pieces
+// of the tile's slot straight to its place in the stream, reading only the bytes that exist.
+__global__ __launch_bounds__(1024) void yk_pack_kernel(const uint8_t* __restrict__ tileCount, const uint16_t* __restrict__ tileDef, const uint2* __restrict__ tileInfo,
+                                                       const uint8_t* __restrict__ slots, size_t T8, const uint32_t* __restrict__ blockSums, int nBlocks,
+                                                       uint16_t* __restrict__ defsOut, uint32_t* __restrict__ nibOut, size_t nibStrideWords, YkFrameStrides fs,
+                                                       const uint32_t* __restrict__ blockCnt, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tmp[32];
+    __shared__ unsigned long long s_pre[17];
     __shared__ uint32_t s_off[YK_SCAN_TILE];
     __shared__ uint8_t s_cnt[YK_SCAN_TILE];
     {   // blockIdx.z = frame of a batch
         const size_t f = blockIdx.z;
         tileCount += f * fs.tileCount; tileDef += f * fs.tileDef; slots += f * fs.slots; blockSums += f * fs.blockN;
+        if (tileInfo) tileInfo += f * fs.tileInfo;
         defsOut += f * fs.defsOut; nibOut += f * (fs.nibOut / 4);
+        if (blockCnt) { blockCnt += f * fs.blockN; totals += f * 8; }
     }
-    const int p = blockIdx.y;
+    // Second scan level inside this kernel (second-generation fused kernel: the per-block sums come from yk_scan1r_kernel): the workgroup adds the
+    // sums of the blocks in front of it (at most 8 KB from L2) instead of waiting for a one-workgroup kernel in the frame's chain of launches.
+    uint32_t preN = 0, preD = 0;
+    if (blockCnt) {
+        unsigned long long acc = 0;                                               // coded tiles << 32 | nibbles
+        for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) { const uint2 v = reinterpret_cast<const uint2*>(blockCnt)[k]; acc += ((unsigned long long)v.y << 32) | v.x; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) acc += __shfl_xor(acc, d);
+        if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; k++) t += s_pre[k]; s_pre[16] = t; }
+        __syncthreads();
+        preN = (uint32_t)s_pre[16]; preD = (uint32_t)(s_pre[16] >> 32);
+        if (blockIdx.x == (unsigned)nBlocks - 1 && threadIdx.x < 3) {            // the totals of the three planes (identical)
+            const uint2 v = reinterpret_cast<const uint2*>(blockCnt)[nBlocks - 1];
+            totals[threadIdx.x * 2] = preD + v.y; totals[threadIdx.x * 2 + 1] = preN + v.x;
+        }
+    }
     const size_t i0 = (size_t)blockIdx.x * YK_SCAN_TILE;
     {
         const size_t i = i0 + threadIdx.x;
-        const uint32_t c = (i < T8) ? tileCount[p * T8 + i] : 0;
+        // second-generation fused kernel: one record per tile {def0 | def1 << 16, def2 | count << 16}; first generation: count and definition arrays
+        uint32_t c = 0, d01 = 0, d2 = 0;
+        if (i < T8) {
+            if (tileInfo) { const uint2 ti = tileInfo[i]; c = ti.y >> 16; d01 = ti.x; d2 = ti.y & 0xFFFFu; }
+            else { c = tileCount[i]; if (c) { d01 = (uint32_t)tileDef[i] | ((uint32_t)tileDef[T8 + i] << 16); d2 = tileDef[2 * T8 + i]; } }
+        }
         uint32_t totN, totD;
         const uint32_t en = yk_block_exscan(c, s_tmp, &totN);
         const uint32_t ed = yk_block_exscan(c ? 1u : 0u, s_tmp, &totD);
-        const uint32_t baseN = blockSums[(size_t)blockIdx.x * 2], baseD = blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
-        s_off[threadIdx.x] = (baseN + en) >> 1;                                   // byte offset inside the plane's stream
+        const uint32_t baseN = blockCnt ? preN : blockSums[(size_t)blockIdx.x * 2], baseD = blockCnt ? preD : blockSums[(size_t)blockIdx.x * 2 + 1];     // same for the three planes
+        s_off[threadIdx.x] = (baseN + en) >> 1;                                   // byte offset inside a plane's stream
         s_cnt[threadIdx.x] = (uint8_t)c;
-        if (c) defsOut[p * T8 + baseD + ed] = tileDef[p * T8 + i];
+        if (c) {
+            defsOut[baseD + ed] = (uint16_t)d01; defsOut[T8 + baseD + ed] = (uint16_t)(d01 >> 16); defsOut[2 * T8 + baseD + ed] = (uint16_t)d2;
+        }
     }
     __syncthreads();
-    uint8_t* out = reinterpret_cast<uint8_t*>(nibOut + (size_t)p * nibStrideWords);
     const int piece = threadIdx.x & 3;
-    for (int it = 0; it < 4; it++) {
-        const int t = it * 256 + (threadIdx.x >> 2);
-        const size_t i = i0 + t;
-        if (i >= T8) break;
-        if (piece * 8 < (s_cnt[t] >> 1))
-            *reinterpret_cast<uint2*>(out + s_off[t] + piece * 8) = *reinterpret_cast<const uint2*>(slots + ((size_t)p * T8 + i) * YK_SLOT + piece * 8);
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        uint8_t* out = reinterpret_cast<uint8_t*>(nibOut + (size_t)p * nibStrideWords);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int t = it * 256 + (threadIdx.x >> 2);
+            const size_t i = i0 + t;
+            if (i < T8 && piece * 8 < (s_cnt[t] >> 1))
+                *reinterpret_cast<uint2*>(out + s_off[t] + piece * 8) = *reinterpret_cast<const uint2*>(slots + ((size_t)p * T8 + i) * YK_SLOT + piece * 8);
+        }
     }
 }
 
@@ -233,6 +297,15 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
     P.xBB64 = (c->fullW + 63) / 64; P.yBB64 = (c->h + 63) / 64; P.xBB32 = (c->fullW + 31) / 32; P.yBB32 = (c->h + 31) / 32;
     P.nFrames = batch ? c->nFrames : 1; P.fs = c->fs;
     P.qtab = c->qtab;
+    P.small = c->B.small;                                       // frame f of an array sits at its offset + f * stride (yk_alloc_image)
+    for (int i = 0; i < 7; i++) P.oBm[i] = (uint32_t)(c->B.bitmap[i] - c->B.small);
+    P.oBm0b = (uint32_t)(c->B.bm0b - c->B.small); P.oCov = (uint32_t)(reinterpret_cast<uint8_t*>(c->B.coverage) - c->B.small);
+    P.oInfo = (uint32_t)(reinterpret_cast<uint8_t*>(c->B.tileInfo) - c->B.small); P.oRun = (uint32_t)(reinterpret_cast<uint8_t*>(c->B.runSums) - c->B.small);
+    if (!batch && c->curFrame) {                                // a selected frame of a batch encoded on its own
+        for (int i = 0; i < 7; i++) P.oBm[i] += (uint32_t)(c->curFrame * c->fs.bitmap[i]);
+        P.oBm0b += (uint32_t)(c->curFrame * c->fs.bm0b); P.oCov += (uint32_t)(c->curFrame * c->fs.coverage * 2);
+        P.oInfo += (uint32_t)(c->curFrame * c->fs.tileInfo * 8); P.oRun += (uint32_t)(c->curFrame * c->fs.runSums * 4);
+    }
     if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
     // version 1 = the cross-check implementation of the test suite (tests/csrc/yk_encode_v1.hip), registered at run time
     if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
@@ -247,9 +320,24 @@ int yk_launch_pack(yk_ctx* c, bool batch) {
     uint32_t* blockCnt = batch ? c->B.blockCnt : c->blockCnt; uint32_t* blockSums = batch ? c->B.blockSums : c->blockSums;
     uint32_t* totals = batch ? c->B.totals : c->totals; uint8_t* nibOut = batch ? c->B.nibOut : c->nibOut;
     if (c->kernelVersion != 2) hipLaunchKernelGGL(yk_scan1_kernel, dim3(nb), dim3(1024), 0, c->stream, c->tileCount, T8, c->blockCnt);
-    hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals, (unsigned long long)c->fs.blockN);
-    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 3, F), dim3(1024), 0, c->stream, batch ? c->B.tileCount : c->tileCount, batch ? c->B.tileDef : c->tileDef,
-                       batch ? c->B.slots : c->slots, T8, blockSums, nb, batch ? c->B.defsOut : c->defsOut, reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, c->fs);
+    // second-generation fused kernel: per-run sums and per-strip 16x16 bytes instead of atomics, per-tile records instead of count / definition arrays
+    const bool v2 = c->kernelVersion == 2;
+    const size_t f0 = batch ? 0 : (size_t)c->curFrame;
+    const uint32_t* runSums = (v2 && (c->tilesW & 7) == 0) ? c->B.runSums + f0 * c->fs.runSums : nullptr;
+    const uint8_t* bm0b = v2 ? c->B.bm0b + f0 * c->fs.bm0b : nullptr;
+    const uint2* tileInfo = v2 ? c->B.tileInfo + f0 * c->fs.tileInfo : nullptr;
+    const int nB64 = ((c->fullW + 63) / 64) * ((c->h + 63) / 64);
+    if (v2) {
+        const int nRuns = (int)((T8 + 7) / 8), n4 = (nRuns + 3) >> 2;
+        const int items = runSums ? (n4 > nB64 ? n4 : nB64) : nB64;
+        hipLaunchKernelGGL(yk_scan1r_kernel, dim3((unsigned)((items + 1023) / 1024), F), dim3(1024), 0, c->stream, runSums, (unsigned long long)c->fs.runSums, nRuns,
+                           blockCnt, (unsigned long long)c->fs.blockN, nb, bm0b, (unsigned long long)c->fs.bm0b,
+                           batch ? c->B.bitmap[0] : c->bitmap[0], (unsigned long long)c->fs.bitmap[0], nB64);
+    }
+    if (!runSums) hipLaunchKernelGGL(yk_scan2_kernel, dim3(F), dim3(1024), 0, c->stream, blockCnt, blockSums, nb, totals, (unsigned long long)c->fs.blockN);
+    hipLaunchKernelGGL(yk_pack_kernel, dim3(nb, 1, F), dim3(1024), 0, c->stream, batch ? c->B.tileCount : c->tileCount, batch ? c->B.tileDef : c->tileDef, tileInfo,
+                       batch ? c->B.slots : c->slots, T8, blockSums, nb, batch ? c->B.defsOut : c->defsOut, reinterpret_cast<uint32_t*>(nibOut), c->nibStride / 4, c->fs,
+                       runSums ? blockCnt : (const uint32_t*)nullptr, totals);
     YK_HIP(c, hipGetLastError());
     return YK_OK;
 }
