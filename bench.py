@@ -847,7 +847,7 @@ def main() -> int:
                           "what": "whole frame per GPU: 16 B/pixel of int32 planes read once + alpha bitmap + 7 bitmaps + defs + nibbles, over ms_per_step / frames per step"},
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "yk_encode2_kernel", "kernel_ms": round(kms["encode"], 4), "algorithmic_bytes": int(alg_bytes),
-                "other_kernels_ms": {"alpha (memset+yk_alpha_kernel+yk_alpha_bbox_kernel)": round(kms["alpha"], 4), "scan+pack (2 kernels)": round(kms["pack"], 4)}}
+                "other_kernels_ms": {"alpha (16-int copy + yk_alpha_kernel)": round(kms["alpha"], 4), "scan+pack (yk_scan1r_kernel + yk_pack_kernel)": round(kms["pack"], 4)}}
     if valu and kms["encode"] > 0:
         # the bound this kernel actually runs against: VALU issue.  Informational; `frac` above stays the HBM figure of the contract
         roofline["valu_issue"] = {"wave_instructions": int(valu), "cycles_per_instruction": 4.15, "simds": 1024, "clock_ghz": 2.2,

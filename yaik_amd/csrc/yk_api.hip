@@ -31,7 +31,7 @@ void yk_rebase(yk_ctx* c, int f) {
 static void yk_free_image(yk_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     auto& B = c->B;
-    F(B.keep); F(B.bounds);
+    F(B.keep); F(B.bounds); F(c->alphaUnitBox); F(c->alphaArrive);
     F(B.small);                                                 // bitmaps, coverage, tile records, run sums: one allocation
     for (int i = 0; i < 7; i++) B.bitmap[i] = nullptr;
     B.coverage = nullptr; B.bm0b = nullptr; B.tileInfo = nullptr; B.runSums = nullptr;
@@ -57,9 +57,12 @@ static int yk_alloc_image(yk_ctx* c) {
     fs.keep = up(MT + 4, 16);                                   // read as 4-byte words by yk_alpha_bbox_kernel
     YK_HIP(c, hipMalloc(&B.keep, fs.keep * F + 16));
     YK_HIP(c, hipMalloc(&B.bounds, 16 * sizeof(int32_t) * F));
-    // The fused kernel's small outputs share ONE allocation (lanes holding different outputs then share a store instruction: scalar base + 32-bit
-    // lane offset, yk_encode2.hip): the seven bitmaps, the strips' 16x16 bytes, the coverage words, the per-tile records, the per-run sums;
-    // each array holds its nFrames copies back to back, 256-byte aligned.
+    {
+        const size_t nUnits = (size_t)((c->fullW / 4 + 255) / 256) * c->mtH, nGroups = (nUnits + 63) / 64;
+        YK_HIP(c, hipMalloc(&c->alphaUnitBox, (nUnits + nGroups) * F * 4 * sizeof(int) + 16));
+        YK_HIP(c, hipMalloc(&c->alphaArrive, (nGroups + 1) * F * sizeof(uint32_t) + 16));
+        YK_HIP(c, hipMemset(c->alphaArrive, 0, (nGroups + 1) * F * sizeof(uint32_t) + 16));
+    }
     static const int sh[7][2] = { {4,4},{4,3},{3,4},{3,3},{3,2},{2,3},{2,2} };
     size_t cur = 0, oBm[7], oBm0b, oCov, oInfo, oRun;
     auto place = [&](size_t bytesPerFrame) { const size_t o = cur; cur = up(cur + bytesPerFrame * F + 16, 256); return o; };
@@ -354,8 +357,9 @@ static int yk_fetch_alpha(yk_ctx* c, std::vector<uint8_t>& keep, int32_t b[5]) {
     YK_HIP(c, hipSetDevice(c->device));
     keep.resize((size_t)c->mtW * c->mtH);
     YK_HIP(c, hipMemcpyAsync(keep.data(), c->keep, keep.size(), hipMemcpyDeviceToHost, c->stream));
-    YK_HIP(c, hipMemcpyAsync(b, c->bounds, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    YK_HIP(c, hipMemcpyAsync(b, c->bounds + c->boundsOff, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
+    b[4] = (b[0] == 0 && b[1] == 0 && b[2] == c->fullW && b[3] == c->fullH) ? 1 : 0;      // "bbox == whole image -> every reject discarded" (EncoderContext.cpp:1294, :1400-1403)
     return YK_OK;
 }
 

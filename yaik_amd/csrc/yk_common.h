@@ -32,7 +32,7 @@ struct YkEncodeParams {
     int ablate;             // timing-only ablation switches (yk_set_ablation); 0 in every product run
     // alpha / bounds (device memory, written by the alpha kernels)
     const uint8_t* keep;    // per 16x16 macro-tile keep flag of this stripe, nullptr = no alpha plane
-    const int32_t* bounds;  // [0..3] boundX0,Y0,X1,Y1 (full-image pixels), [4] discardRejects
+    const int32_t* bounds;  // [0..3] boundX0,Y0,X1,Y1 of the kept tiles (full-image pixels; yk_encode2_kernel derives the discard rule from them), [4] discardRejects for the first-generation kernel
     // outputs
     uint8_t* bitmap[7];
     uint16_t* coverage;     // per macro-tile, bit = cellY*4+cellX
@@ -79,7 +79,10 @@ struct yk_ctx {
     int32_t* ownedPlanes = nullptr; size_t ownedPlanesBytes = 0;
     // alpha
     uint8_t* keep = nullptr;            // mtW*mtH
-    int32_t* bounds = nullptr;          // 16 ints: [0..3] global bounds, [4] discard flag, [8..11] stripe bbox accumulators
+    int32_t* bounds = nullptr;          // 16 ints: [0..4] the host-combined box of a striped image + its discard flag (yk_alpha_finish), [8..11] the box yk_alpha_kernel accumulates
+    int* alphaUnitBox = nullptr;        // yk_alpha_kernel: one box {x0, y0, x1, y1} per work unit (tile row x 1024-pixel segment) and frame
+    uint32_t* alphaArrive = nullptr;    // its arrival counters: per group of 64 units + one per frame (zero between launches)
+    int boundsOff = 8;                  // where the image-wide box is: 8 (whole image, batch) or 0 (stripes, after yk_alpha_finish)
     bool alphaDone = false, alphaFinished = false;
     int32_t hostBounds[4] = {0, 0, 0, 0}; int hostDiscard = 1, hostHasChunk = 0;
     // encode outputs

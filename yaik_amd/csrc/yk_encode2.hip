@@ -849,7 +849,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     int cxB = 0, cyB = 0, cw = w, chh = P.fullH, discard = 1;                 // constraint box of DynamicTileEncode (:4386-4391)
     if (boundsP) {
         const int b0 = boundsP[0], b1 = boundsP[1], b2 = boundsP[2], b3 = boundsP[3];
-        discard = boundsP[4];
+        discard = (b0 == 0 && b1 == 0 && b2 == w && b3 == P.fullH) ? 1 : 0;    // bbox == whole image: every reject is discarded (EncoderContext.cpp:1294, :1400-1403)
         cxB = (b0 >> 3) << 3; cyB = (b1 >> 3) << 3;
         cw = (((b2 + 7) >> 3) << 3) - cxB; chh = (((b3 + 7) >> 3) << 3) - cyB;
     }

@@ -14,91 +14,129 @@
 #include "yk_device.h"
 
 // ------------------------------------------------------------------------------------------------------------------
-// a9: alpha tile-reject, stage 1.  keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed
-// form of quadRecursion with maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (:416-422).
+// a9: alpha tile-reject.  keep[mt] = 1 iff any of the 256 alphas of the aligned 16x16 block is non-zero (closed form of
+// quadRecursion with maxMipLevel 3, EncoderContext.cpp:394-423); kept blocks grow the bounding box (boundingL/T/R/B, :416-422).
 //
-// The plane is streamed in memory order like a reduction: a work unit is (row, 4096-pixel segment), every lane has four
-// 16-byte loads in flight and a wave instruction covers 1 KB of one row.  Four adjacent lanes hold the 16 pixels of one
-// tile row; a non-zero group raises the tile's flag with an idempotent byte store into the pre-zeroed map, so the
-// streaming path has no atomics.  The bounding box is derived from the flags afterwards (yk_alpha_bbox_kernel).
+// ONE kernel (round 3: a clear of the flag map, a flagging kernel over single image rows with idempotent byte stores, and a
+// bounding-box kernel over the flags -- three stream operations in every frame's chain of short kernels).  A work unit is
+// (row of 16x16 tiles, 1024-pixel segment): the workgroup owns its 64 tiles, so it writes their flags outright (nothing to
+// clear) and knows their box.  The plane is streamed with 16-byte loads, eight in flight per lane, a wave instruction covering
+// 1 KB of one row; four adjacent lanes hold the 16 columns of one tile: 268 MB in 41 us = 6.5 TB/s without the box.
+// The image-wide box WITHOUT atomics on its four words (every form of guarded atomicMin / atomicMax on them, dealt from the image's
+// outside inwards or not, cost 23-85 us: a single address sustains ~88 atomics per microsecond, coherent guard reads are served by
+// the same L2 channel one after the other): every unit leaves its box in a slot of its own (write-through store), arrivals are
+// counted per group of 64 units and then per frame (<= 64 atomics per address), and the workgroup that arrives last folds the
+// slots into bounds[8..11] = {min x0, min y0, max x1, max y1} ({9999999, 9999999, -1, -1} when nothing is kept).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h,
-                                                       uint8_t* __restrict__ keep0, int mtW, int32_t* __restrict__ bounds,
-                                                       int nFrames, unsigned long long planeStride, unsigned long long keepStride) {
-    // accumulators of the bounding-box kernel that follows on the stream: {x0,y0,x1,y1} = empty, done-counter = 0 (one set per frame)
-    for (int f = blockIdx.x; f < nFrames; f += gridDim.x)
-        if (threadIdx.x < 5) bounds[(size_t)f * 16 + 8 + threadIdx.x] = threadIdx.x < 2 ? 9999999 : (threadIdx.x < 4 ? -1 : 0);
-    const int lane = threadIdx.x & 63;
+typedef int yk_i4 __attribute__((ext_vector_type(4)));
+#ifndef YK_ALPHA_INFLIGHT
+#define YK_ALPHA_INFLIGHT 8                                                  // 16-byte loads a lane has in flight (two batches per unit)
+#endif
+__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h, int y0,
+                                                       uint8_t* __restrict__ keep0, int mtW, int mtH, int32_t* __restrict__ bounds,
+                                                       int nFrames, unsigned long long planeStride, unsigned long long keepStride,
+                                                       int* __restrict__ unitBox0, uint32_t* __restrict__ arrive0) {
+    __shared__ int s_box[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
-    const int nSeg = (vecPerRow + 1023) >> 10;
-    const int nUnits = nSeg * h;
+    const int nSeg = (vecPerRow + 255) >> 8;                     // 256 int4 = 1024 pixels per segment
+    const int nUnits = nSeg * mtH, nGroups = (nUnits + 63) >> 6;
     for (long long uu = blockIdx.x; uu < (long long)nUnits * nFrames; uu += gridDim.x) {
         const int f = (int)(uu / nUnits), u = (int)(uu - (long long)f * nUnits);
         const int32_t* alpha = alpha0 + (size_t)f * planeStride;
         uint8_t* keep = keep0 + (size_t)f * keepStride;
-        const int y = u / nSeg, seg = u - y * nSeg;
-        const int32_t* row = alpha + (size_t)y * strideElems;
-        int4 a[4];
+        int* unitBox = unitBox0 + (size_t)f * (nUnits + nGroups) * 4;
+        uint32_t* arrive = arrive0 + (size_t)f * (nGroups + 1);
+        const int ty = u / nSeg, seg = u - ty * nSeg;
+        const int xv = seg * 256 + (int)threadIdx.x;
+        const int32_t* col = alpha + (size_t)(ty * 16) * strideElems + (size_t)xv * 4;
+        const bool inX = xv < vecPerRow;
+        int nz = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int xv = seg * 1024 + k * 256 + threadIdx.x;
-            a[k] = make_int4(0, 0, 0, 0);
-            if (xv < vecPerRow) a[k] = *reinterpret_cast<const int4*>(row + xv * 4);
-        }
+        for (int kb = 0; kb < 16 / YK_ALPHA_INFLIGHT; kb++) {
+            yk_i4 a[YK_ALPHA_INFLIGHT];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int xv = seg * 1024 + k * 256 + threadIdx.x;
-            const unsigned long long b = __ballot((a[k].x | a[k].y | a[k].z | a[k].w) != 0);
-            if ((lane & 3) == 0 && ((b >> lane) & 0xFULL) != 0) keep[(size_t)(y >> 4) * mtW + (xv >> 2)] = 1;
+            for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) {
+                const int y = ty * 16 + kb * YK_ALPHA_INFLIGHT + k;
+                a[k] = (yk_i4){0, 0, 0, 0};
+                if (inX && y < h) a[k] = __builtin_nontemporal_load(reinterpret_cast<const yk_i4*>(col + (size_t)(kb * YK_ALPHA_INFLIGHT + k) * strideElems));
+            }
+#pragma unroll
+            for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) nz |= a[k].x | a[k].y | a[k].z | a[k].w;
         }
+        const unsigned long long b = __ballot(nz != 0);
+        const bool tileLane = (lane & 3) == 0;
+        const bool kept = ((b >> (lane & ~3)) & 0xFULL) != 0;
+        const int tx = xv >> 2;
+        if (tileLane && tx < mtW) keep[(size_t)ty * mtW + tx] = kept ? 1 : 0;
+        // the unit's box of kept tiles (tile columns; its tile row is ty)
+        const unsigned long long kb64 = __ballot(tileLane && kept && tx < mtW);
+        if (lane == 0) {
+            const int t0 = seg * 64 + wv * 16;
+            s_box[wv][0] = kb64 ? t0 + ((__ffsll((long long)kb64) - 1) >> 2) : 0x7FFFFFFF;
+            s_box[wv][1] = kb64 ? t0 + ((63 - __clzll((long long)kb64)) >> 2) : -1;
+        }
+        __syncthreads();
+        // Only the first wave takes part in the arrival protocol (its round trips -- store acknowledged, then one or two returning atomics -- are
+        // 4-5 us at the end of a 20 us workgroup); the other three go on (to their next unit, or out).  s_box is read before anything slow, and the
+        // next iteration's barrier in front of its writes keeps the waves in step.
+        if (wv == 0) {
+            // unit boxes live in unitBox[0 .. nUnits), group boxes behind them; a box = two 64-bit words {x0 | y0 << 32, x1 | y1 << 32}, written
+            // through to memory (the XCDs' L2s are not coherent with each other) and acknowledged before its owner counts as arrived
+            unsigned long long* ub = reinterpret_cast<unsigned long long*>(unitBox);
+            auto putBox = [&](const int slot, const int bx0, const int by0, const int bx1, const int by1) {
+                __hip_atomic_store(&ub[slot * 2], ((unsigned long long)(uint32_t)by0 << 32) | (uint32_t)bx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ub[slot * 2 + 1], ((unsigned long long)(uint32_t)by1 << 32) | (uint32_t)bx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0);                                      // vmcnt(0): both stores have been acknowledged
+            };
+            auto foldBoxes = [&](const int first, const int n, int& x0, int& gy0, int& x1, int& gy1) {   // the whole wave: boxes [first, first + n)
+                x0 = 9999999; gy0 = 9999999; x1 = -1; gy1 = -1;
+                for (int k = lane; k < n; k += 64) {
+                    const unsigned long long a = __hip_atomic_load(&ub[(first + k) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long bb = __hip_atomic_load(&ub[(first + k) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x0 = min(x0, (int)(uint32_t)a); gy0 = min(gy0, (int)(uint32_t)(a >> 32)); x1 = max(x1, (int)(uint32_t)bb); gy1 = max(gy1, (int)(uint32_t)(bb >> 32));
+                }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    x0 = min(x0, __shfl_xor(x0, d)); x1 = max(x1, __shfl_xor(x1, d));
+                    gy0 = min(gy0, __shfl_xor(gy0, d)); gy1 = max(gy1, __shfl_xor(gy1, d));
+                }
+            };
+            const int g = u >> 6, inGroup = min(64, nUnits - (g << 6));
+            uint32_t lastOfGroup = 0;
+            if (lane == 0) {
+                const int lo = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+                const int hi = max(max(s_box[0][1], s_box[1][1]), max(s_box[2][1], s_box[3][1]));
+                const bool any = hi >= 0;
+                putBox(u, any ? lo * 16 : 9999999, any ? y0 + ty * 16 : 9999999, any ? hi * 16 + 16 : -1, any ? y0 + ty * 16 + 16 : -1);
+                lastOfGroup = __hip_atomic_fetch_add(&arrive[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)inGroup - 1u ? 1u : 0u;
+            }
+            if (__builtin_amdgcn_readfirstlane((int)lastOfGroup)) {                  // the group's 64 boxes -> its group box (one round trip, anywhere in the launch)
+                int x0, gy0, x1, gy1;
+                foldBoxes(g << 6, inGroup, x0, gy0, x1, gy1);
+                uint32_t lastOfFrame = 0;
+                if (lane == 0) {
+                    putBox(nUnits + g, x0, gy0, x1, gy1);
+                    arrive[g] = 0u;                                                  // for the next frame (nobody else touches it any more)
+                    lastOfFrame = __hip_atomic_fetch_add(&arrive[nGroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nGroups - 1u ? 1u : 0u;
+                }
+                if (__builtin_amdgcn_readfirstlane((int)lastOfFrame)) {              // every unit of the frame has arrived: the group boxes -> the image's box
+                    foldBoxes(nUnits, nGroups, x0, gy0, x1, gy1);
+                    if (lane == 0) { int32_t* acc = bounds + (size_t)f * 16 + 8; acc[0] = x0; acc[1] = gy0; acc[2] = x1; acc[3] = gy1; arrive[nGroups] = 0u; }
+                }
+            }
+        }
+        if (uu + gridDim.x < (long long)nUnits * nFrames) __syncthreads();          // another unit follows: s_box is reused
     }
 }
 
-// bounding box of the kept 16x16 tiles (quadRecursion's boundingL/T/R/B, EncoderContext.cpp:416-422) from the keep flags;
-// one atomic per workgroup and bound (a single address only sustains ~88 atomics/us).  The last workgroup to finish also
-// publishes the whole-image form: bounds[0..3] = the box, bounds[4] = "bbox == whole image -> every reject discarded"
-// (EncoderContext.cpp:1294, :1400-1403); a stripe caller overrides these five ints with the host-combined box.
-__global__ __launch_bounds__(256) void yk_alpha_bbox_kernel(const uint32_t* __restrict__ keep4, int mtW, int mtH, int y0, int32_t* __restrict__ bounds,
-                                                            int fullW, int fullH, unsigned long long keepStrideWords) {
-    __shared__ int s_red[4][4];
-    keep4 += (size_t)blockIdx.y * keepStrideWords;               // blockIdx.y = frame of a batch
-    bounds += (size_t)blockIdx.y * 16;
-    int32_t* bbox = bounds + 8;
-    int x0 = 9999999, x1 = -1, gy0 = 9999999, gy1 = -1;
-    const int n = mtW * mtH, n4 = (n + 3) >> 2;                  // four 1-byte flags per load (the map is padded to a multiple of 4)
-    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
-        uint32_t f = keep4[i4];
-        if (!f) continue;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = i4 * 4 + k;
-            if (((f >> (8 * k)) & 255u) && i < n) {
-                const int my = i / mtW, mx = i - my * mtW;
-                x0 = min(x0, mx * 16); x1 = max(x1, mx * 16 + 16);
-                gy0 = min(gy0, y0 + my * 16); gy1 = max(gy1, y0 + my * 16 + 16);
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        x0 = min(x0, __shfl_xor(x0, d)); x1 = max(x1, __shfl_xor(x1, d));
-        gy0 = min(gy0, __shfl_xor(gy0, d)); gy1 = max(gy1, __shfl_xor(gy1, d));
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[wave][0] = x0; s_red[wave][1] = gy0; s_red[wave][2] = x1; s_red[wave][3] = gy1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) {
-            x0 = min(x0, s_red[k][0]); gy0 = min(gy0, s_red[k][1]); x1 = max(x1, s_red[k][2]); gy1 = max(gy1, s_red[k][3]);
-        }
-        if (x1 >= 0) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], gy0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], gy1); }
-        __threadfence();
-        if (atomicAdd(&bbox[4], 1) == (int)gridDim.x - 1) {       // every other workgroup's atomics are visible now
-            const int bx0 = atomicAdd(&bbox[0], 0), by0 = atomicAdd(&bbox[1], 0), bx1 = atomicAdd(&bbox[2], 0), by1 = atomicAdd(&bbox[3], 0);
-            bounds[0] = bx0; bounds[1] = by0; bounds[2] = bx1; bounds[3] = by1;
-            bounds[4] = (bx0 == 0 && by0 == 0 && bx1 == fullW && by1 == fullH) ? 1 : 0;
-        }
-    }
+// test path only (the first-generation cross-check kernel reads the published form): bounds[0..3] = the box, bounds[4] = "bbox == whole image ->
+// every reject discarded" (EncoderContext.cpp:1294, :1400-1403).  The library's own kernel derives the flag from the box.
+__global__ void yk_alpha_publish_kernel(int32_t* __restrict__ bounds, int srcOff, int fullW, int fullH) {
+    bounds += (size_t)blockIdx.x * 16;
+    const int b0 = bounds[srcOff], b1 = bounds[srcOff + 1], b2 = bounds[srcOff + 2], b3 = bounds[srcOff + 3];
+    bounds[0] = b0; bounds[1] = b1; bounds[2] = b2; bounds[3] = b3;
+    bounds[4] = (b0 == 0 && b1 == 0 && b2 == fullW && b3 == fullH) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -258,25 +296,22 @@ int yk_launch_alpha(yk_ctx* c, bool batch) {
     uint8_t* keep = batch ? c->B.keep : c->keep;
     int32_t* bounds = batch ? c->B.bounds : c->bounds;
     const int32_t* alpha = batch ? c->B.plane[3] : c->plane[3];
-    const size_t nFlags = ((size_t)c->mtW * c->mtH + 3) & ~(size_t)3;
-    YK_HIP(c, hipMemsetAsync(keep, 0, F > 1 ? (size_t)c->fs.keep * F : nFlags, c->stream));
-    const long long nUnits = (long long)((c->fullW / 4 + 1023) / 1024) * c->h * F;
-    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < 4096 ? nUnits : 4096)), dim3(256), 0, c->stream, alpha, c->strideElems, c->fullW, c->h,
-                       keep, c->mtW, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep);
+    const int nSeg = (c->fullW / 4 + 255) / 256;
+    const long long nUnits = (long long)nSeg * c->mtH * F;
+    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < 4096 ? nUnits : 4096)), dim3(256), 0, c->stream, alpha, c->strideElems, c->fullW, c->h, c->y0,
+                       keep, c->mtW, c->mtH, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep, c->alphaUnitBox, c->alphaArrive);
     YK_HIP(c, hipGetLastError());
-    const int nb = (int)((nFlags / 4 + 1023) / 1024);
-    hipLaunchKernelGGL(yk_alpha_bbox_kernel, dim3(nb < 128 ? nb : 128, F), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(keep), c->mtW, c->mtH,
-                       c->y0, bounds, c->fullW, c->fullH, (unsigned long long)(c->fs.keep / 4));
-    YK_HIP(c, hipGetLastError());
+    c->boundsOff = 8;                                           // whole image / batch: the accumulators are the box; a stripe caller replaces it (yk_alpha_finish)
     return YK_OK;
 }
 
 int yk_launch_alpha_finish(yk_ctx* c, const int32_t* globalBBox) {
-    // whole image: yk_alpha_bbox_kernel already published bounds[0..4]; stripes: the host-combined box replaces them
+    // whole image: the box is where yk_alpha_kernel accumulated it; stripes: the host-combined box goes to bounds[0..4]
     if (globalBBox) {
         int32_t b[5] = { globalBBox[0], globalBBox[1], globalBBox[2], globalBBox[3], 0 };
         b[4] = (b[0] == 0 && b[1] == 0 && b[2] == c->fullW && b[3] == c->fullH) ? 1 : 0;
         YK_HIP(c, hipMemcpyAsync(c->bounds, b, sizeof b, hipMemcpyHostToDevice, c->stream));
+        c->boundsOff = 0;
     }
     return YK_OK;
 }
@@ -287,7 +322,7 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
     P.strideElems = c->strideElems; P.w = c->fullW; P.h = c->h; P.hAvail = c->h + c->halo; P.y0 = c->y0; P.fullH = c->fullH;
     P.rejectFactor = rejectFactor; P.startMode = mode3BitOnly ? 3 : 0; P.wantDst = wantDst; P.ablate = c->ablate;
     P.keep = (c->nPlanes == 4) ? (batch ? c->B.keep : c->keep) : nullptr;
-    P.bounds = (c->nPlanes == 4) ? (batch ? c->B.bounds : c->bounds) : nullptr;
+    P.bounds = (c->nPlanes == 4) ? (batch ? c->B.bounds : c->bounds) + c->boundsOff : nullptr;   // {x0, y0, x1, y1}; the kernel derives the discard rule
     for (int i = 0; i < 7; i++) P.bitmap[i] = batch ? c->B.bitmap[i] : c->bitmap[i];
     P.coverage = batch ? c->B.coverage : c->coverage; P.tileDef = batch ? c->B.tileDef : c->tileDef;
     P.tileCount = batch ? c->B.tileCount : c->tileCount; P.slots = batch ? c->B.slots : c->slots;
@@ -309,6 +344,10 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
     if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
     // version 1 = the cross-check implementation of the test suite (tests/csrc/yk_encode_v1.hip), registered at run time
     if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");
+    if (c->nPlanes == 4) {                                      // it reads the published form bounds[0..4]
+        hipLaunchKernelGGL(yk_alpha_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->bounds, c->boundsOff, c->fullW, c->fullH);
+        P.bounds = c->bounds;
+    }
     if (!g_crossCheckLauncher) return yk_fail(c, YK_ERR_STATE, "kernel version 1 is not part of this library: register it with yk_set_cross_check_launcher");
     if (g_crossCheckLauncher(c->stream, &P) != 0) return yk_fail(c, YK_ERR_HIP, "cross-check kernel launch", hipGetLastError());
     return YK_OK;
