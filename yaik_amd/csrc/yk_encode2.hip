@@ -605,6 +605,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
     float* const s_err = reinterpret_cast<float*>(s_aux + 408);
     __shared__ uint32_t s_range[3 * 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_sp[3 * 4 * 8 + 3 * 4 * 16];      // strips with at most four cells to code: six sums and sixteen index words per plane and cell
+
     uint32_t* const s_tile = s_aux + 416;                                    // exact-order fallback: the 64 values of the tile-plane being re-summed
     // range phase: the index words of a plane's sixteen rows per lane; the staged pixels are dead by then (the test build's LUTs live there)
     __shared__ uint32_t s_iwTest[WANT_DST ? 1024 : 1];
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         // the reciprocals of the range phase's error terms ride along (every strip pays one load and one LDS store; a coded strip used to
         // compute its 256 quotients itself, four correctly rounded divisions per lane)
         const float4 rc4 = *reinterpret_cast<const float4*>(P.qtab + YK2_QBYTES + (size_t)lane * 16);
+
         __builtin_amdgcn_s_setprio(0);                                       // all loads are out
         uint4 o[4], ob;
 #pragma unroll
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         }
         if (lane >= 32 && lane <= 48) s_pix[hr * LS + 64] = hcol;
         *reinterpret_cast<float4*>(&s_rcp[lane * 4]) = rc4;
+
     }
     __syncthreads();                                                         // single-wave workgroup: an LDS fence
     YK2_PROBE(1);
@@ -1003,10 +1006,12 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
         auto issueRows = [&](const int pl, const int k0, const int k1) {
             if (valid && !spread && !YK2_ABLATE(4)) {
                 const uint32_t q16 = (tdef[pl] & 0xFFFFu) << 4;
+                {
 #pragma unroll
-                for (int k = k0; k < k1; k++) {
-                    const uint32_t v4 = y2_byte_x4(pw[k], pl);                   // 4 * value: a quarter of its row offset
-                    win[k] = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + q16));
+                    for (int k = k0; k < k1; k++) {
+                        const uint32_t v4 = y2_byte_x4(pw[k], pl);                   // 4 * value: a quarter of its row offset
+                        win[k] = *reinterpret_cast<const uint4*>(qrows + (size_t)((v4 << 2) + q16));
+                    }
                 }
             }
         };
