@@ -206,6 +206,11 @@ int yk_set_dst_fill(yk_ctx* c, int32_t fill);
  * streams GenerateDynamicTileChunk hands to ZStd (:8524-8576): pixel bytes (planes R,G,B appended, 1 B per pixel) and the
  * per-tile parameter bytes color0,minCol,delta (`streamType`, :8503-8505).  colorCompression1D = 255, rangeCompression1D = 15. */
 int yk_range1d_encode(yk_ctx* c);
+/* enable != 0: from the next yk_encode_tiles on, the fused kernel also leaves the packed pixels of every 4x4 cell it did not cover (4 bytes per
+ * pixel, only those cells) in a cache the 1-D path reads instead of the int32 planes: every input sample is then read from HBM once on the whole
+ * path.  Costs the fused kernel four 16-byte stores per lane of an uncovered cell, so it is off unless a caller runs the 1-D path
+ * (EncoderContext::ConvertHotPath turns it on).  The results of yk_range1d_encode are the same either way.  Not for batches. */
+int yk_set_pixel_cache(yk_ctx* c, int enable);
 int yk_range1d_streams(yk_ctx* c, uint8_t* hostPix, size_t capPix, size_t* nPix, uint8_t* hostType, size_t capType, size_t* nType);
 /* the two streams where they lie in HBM (valid until the handle's next yk_range1d_encode / yk_set_image) and their lengths; synchronises once for the lengths */
 int yk_range1d_streams_device(yk_ctx* c, const uint8_t** devPix, size_t* nPix, const uint8_t** devType, size_t* nType);

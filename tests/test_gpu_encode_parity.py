@@ -76,6 +76,11 @@ def test_gpu_outputs_match_reference_hashes(oracle_built, name):
                 assert sha(defs) == want[f"plnt_defs_{m}_{p}"] and sha(nib) == want[f"plnt_idx_{m}_{p}"], (m, p)
         pix, typ = e.dynamic_tile_compressor()
         assert sha(pix) == want["d1_pix"] and sha(typ) == want["d1_type"]
+        # the same streams when the 1-D path reads the fused kernel's pixel cache (4 B per uncovered pixel) instead of the planes (yk_set_pixel_cache)
+        e.set_pixel_cache(True)
+        e.encode(3, True, False)
+        pix2, typ2 = e.dynamic_tile_compressor()
+        assert sha(pix2) == want["d1_pix"] and sha(typ2) == want["d1_type"]
     finally:
         e.close()
 

@@ -92,3 +92,11 @@ def test_random_tile_regimes_bit_exact(hip, oracle_built, seed):
     opix, otyp = ora.streams_1d()
     gpix, gtyp = hip.dynamic_tile_compressor()
     assert np.array_equal(gpix, opix) and np.array_equal(gtyp, otyp), seed
+    # and through the fused kernel's pixel cache (yk_set_pixel_cache: 4 B per uncovered pixel instead of the planes)
+    hip.set_pixel_cache(True)
+    try:
+        hip.encode(3, True, False)
+        gpix, gtyp = hip.dynamic_tile_compressor()
+        assert np.array_equal(gpix, opix) and np.array_equal(gtyp, otyp), ("pixel cache", seed)
+    finally:
+        hip.set_pixel_cache(False)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "yk_range_dst": (C.c_int, [vp, C.c_int, vp, sz]),
     "yk_set_dst_fill": (C.c_int, [vp, C.c_int32]),
     "yk_range1d_encode": (C.c_int, [vp]),
+    "yk_set_pixel_cache": (C.c_int, [vp, C.c_int]),
     "yk_range1d_streams": (C.c_int, [vp, vp, sz, szp, vp, sz, szp]),
     "yk_range1d_plane_ends": (C.c_int, [vp, vp, vp]),
     "yk_export_capacity": (sz, [vp]),

@@ -44,6 +44,7 @@ static void yk_free_image(yk_ctx* c) {
     F(c->latticeOwner); F(c->cornerStream); F(c->cornerScratch); F(c->cornerEdgeIdx);
     F(c->preview); F(c->covCh); F(c->mapped3); F(c->ppBitmap); F(c->ppStream); F(c->ppScratch); c->ppBitmapBytes = c->ppBitmapCap = 0; c->ppStreamCap = c->ppStreamBytes = 0; c->ppScratchElems = 0;
     F(c->r1Slots); F(c->r1Params); F(c->r1Cnt); F(c->r1Pix); F(c->r1Type); c->r1Ready = false;
+    F(c->pixCache); c->pixCacheValid = false;
     if (c->frameGraph) { (void)hipGraphExecDestroy(c->frameGraph); c->frameGraph = nullptr; }
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
 }
@@ -414,6 +415,13 @@ int yk_set_kernel_version(yk_ctx* c, int version) {
 
 int yk_set_ablation(yk_ctx* c, int flags) { if (!c) return YK_ERR_BAD_ARG; c->ablate = flags; return YK_OK; }
 #endif
+
+int yk_set_pixel_cache(yk_ctx* c, int enable) {
+    if (!c) return YK_ERR_BAD_ARG;
+    c->pixCacheOn = enable != 0;
+    if (!enable) c->pixCacheValid = false;
+    return YK_OK;
+}
 
 int yk_set_dst_fill(yk_ctx* c, int32_t fill) { if (!c) return YK_ERR_BAD_ARG; c->dstFill = fill; return YK_OK; }
 

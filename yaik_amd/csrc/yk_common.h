@@ -51,6 +51,10 @@ struct YkEncodeParams {
     // and the per-run sums {nibbles / 16 | coded tiles << 16} (one per 8 consecutive tiles; widths that are multiples of 8 tiles only)
     uint8_t* small;
     uint32_t oBm[7], oBm0b, oCov, oInfo, oRun;
+    // optional (yk_set_pixel_cache): the packed pixels (0x00BBGGRR) of every 4x4 cell the gradient passes left uncovered, for the live 1-D range
+    // path behind the fused kernel, which then reads 4 bytes per such pixel instead of 12 from the planes: [strip (row-major)][cell row 0..3][lane]
+    // 16-byte pieces, lane in this kernel's (Morton) order.  nullptr = not wanted.
+    uint4* pixCache;
     YkFrameStrides fs;
 };
 
@@ -126,6 +130,7 @@ struct yk_ctx {
     // live 1-D range path (a15)
     uint8_t* r1Slots = nullptr; uint8_t* r1Params = nullptr; uint32_t* r1Cnt = nullptr; uint8_t* r1Pix = nullptr; uint8_t* r1Type = nullptr;
     uint32_t r1Tiles = 0, r1PixCount = 0; bool r1Ready = false;
+    uint4* pixCache = nullptr; bool pixCacheOn = false, pixCacheValid = false;   // yk_set_pixel_cache: uncovered cells' packed pixels, fused kernel -> 1-D path
     uint32_t r1EndTiles[3] = {}, r1EndPix[3] = {};       // cumulative per plane (equal thirds unless a partial-plane pass ran)
     // decode
     int dw = 0, dh = 0; uint8_t* dPlanes = nullptr; size_t dPlaneSize = 0;

@@ -834,6 +834,16 @@ __global__ __launch_bounds__(64, 4) void yk_encode2_kernel(const YkEncodeParams 
             val16 = y2_writelane(bmWord(9 + sx * 2 + (int)w2) >> (16 * w1), 2 + sx, val16);
         }
         if (off16 != ~0u) Y2_STORE_IF(8, *reinterpret_cast<uint16_t*>(small + off16), (uint16_t)val16);
+        // optional: the packed pixels of the cells nothing covered, for the live 1-D path (yk_set_pixel_cache): [strip][cell row][lane] 16-byte pieces
+        if (P.pixCache != nullptr) {
+            const bool cellIn = (gxCell < w) && (gyCell < h);
+            if (cellIn && !((cov >> lane) & 1ULL)) {
+                const uint32_t strip = (uint32_t)((BY * 4 + wave) * P.xBB64 + BX);
+                uint4* dstp = P.pixCache + (size_t)strip * 256 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; r++) dstp[r * 64] = make_uint4(pw[r * 4 + 0], pw[r * 4 + 1], pw[r * 4 + 2], pw[r * 4 + 3]);
+            }
+        }
         // 32-bit words: lane 1 = 8x4 (64x32 swizzle blocks, tile rows 4w..4w+3), lanes 2, 3 = 4x4 (32x32 swizzle blocks); lanes 4, 5 = the run sums
         {
             const bool in = BY * 2 + (int)w2 < P.yBB32;

@@ -19,8 +19,11 @@ __device__ __forceinline__ int yk_r1_div(int n, int d) { return __float2int_rz((
 // counts <= 64), filled with ds_add and read back per pixel; min / max / mode reductions are two xor-shuffles.
 // DIRECT: the stream offsets of every tile are known before the kernel runs (they depend on the coverage alone: yk_r1_offsets_kernel + one scan),
 // so pixel bytes and parameters go straight to their place in the reference's streams -- no per-tile slots, no compaction pass behind it.
-struct R1Direct { const uint32_t* offInBlk; const uint32_t* blockT; const uint32_t* blockP; const uint32_t* totals; uint8_t* pixOut; uint8_t* typeOut; };
-template <bool DIRECT>
+// CACHED: the pixels come from the fused kernel's pixel cache (yk_set_pixel_cache: packed 0x00BBGGRR words of the uncovered cells, 4 B per pixel,
+// [strip][cell row][lane in that kernel's Morton order]) instead of the int32 planes (12 B per pixel): a lane's sixteen pixels are four 16-byte
+// loads, held in registers across the three planes -- no staging through LDS, and every input sample of the whole path is read from HBM once.
+struct R1Direct { const uint32_t* offInBlk; const uint32_t* blockT; const uint32_t* blockP; const uint32_t* totals; uint8_t* pixOut; uint8_t* typeOut; const uint4* pixCache; };
+template <bool DIRECT, bool CACHED = false>
 __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB,
                                                         int strideElems, int w, int h, const uint16_t* __restrict__ coverage, int mtW,
                                                         int tilesW, size_t T8, uint8_t* __restrict__ slots, uint8_t* __restrict__ params,
@@ -75,8 +78,15 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
         const int stw = sq * 4 + (scy >> 1) * 2 + (scx >> 1);
         uint32_t* const shist = &s_hist[stw * 65];
         const int32_t* planesS[3] = { pR, pG, pB };
+        uint32_t spw = 0;                                                    // CACHED: pixel k of the source cell, the three planes in one word
+        if (CACHED && act) {
+            const int sm = sq * 16 + (scy >> 1) * 8 + (scx >> 1) * 4 + (scy & 1) * 2 + (scx & 1);      // the source cell's lane in the fused kernel's order
+            spw = reinterpret_cast<const uint32_t*>(D.pixCache + ((size_t)blockIdx.x * 4 + (k >> 2)) * 64 + sm)[k & 3];
+        }
         for (int p = (onlyPlane < 0 ? 0 : onlyPlane); p < (onlyPlane < 0 ? 3 : onlyPlane + 1); p++) {
-            const int v = act ? (planesS[p][(size_t)(sgy + (k >> 2)) * strideElems + sgx + (k & 3)] & 255) : 0;      // CompressF(v,255) == v
+            int v = 0;                                                           // CompressF(v,255) == v
+            if (CACHED) v = (int)((spw >> (8 * p)) & 255u);
+            else if (act) v = planesS[p][(size_t)(sgy + (k >> 2)) * strideElems + sgx + (k & 3)] & 255;
             __syncthreads();
             // lane-contiguous 16-byte stores (a lane clearing its own 64-byte run put the whole wave on two LDS banks)
             *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0, 0, 0, 0);
@@ -131,7 +141,29 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
     const int posStep = 4 * (cyl ? nBot : nTop);
     const int32_t* planes[3] = { pR, pG, pB };
     const int g4 = (lane & 15) * 4, r0 = lane >> 4;
+    uint4 cpx[4] = {};
+    if (CACHED && valid) {
+        const int m = q * 16 + (cy >> 1) * 8 + (cx >> 1) * 4 + (cy & 1) * 2 + (cx & 1);              // this cell's lane in the fused kernel's order
+        const uint4* src = D.pixCache + (size_t)blockIdx.x * 256 + m;
+#pragma unroll
+        for (int r = 0; r < 4; r++) cpx[r] = src[r * 64];
+    }
     for (int p = (onlyPlane < 0 ? 0 : onlyPlane); p < (onlyPlane < 0 ? 3 : onlyPlane + 1); p++) {
+        uint32_t row[4];
+        if (CACHED) {
+            // byte p of the row's four pixel words
+            const uint32_t sel = 0x0C0C0000u | ((4u + (uint32_t)p) << 8) | (uint32_t)p;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                row[r] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(cpx[r].w, cpx[r].z, sel), __builtin_amdgcn_perm(cpx[r].y, cpx[r].x, sel), 0x05040100u);
+            __syncthreads();                                                 // previous plane's readers of the histograms are done (single wave: LDS fence)
+            *reinterpret_cast<uint4*>(&s_hist[lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[256 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[512 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&s_hist[768 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            if (lane < 4) *reinterpret_cast<uint4*>(&s_hist[1024 + lane * 4]) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        } else
         // ---- stage the strip of this plane as bytes -------------------------------------------------------------
         {
             const int gx = BX * 64 + g4;
@@ -157,9 +189,10 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             if (lane < 4) *reinterpret_cast<uint4*>(&s_hist[1024 + lane * 4]) = make_uint4(0, 0, 0, 0);
             __syncthreads();
         }
-        uint32_t row[4];
+        if (!CACHED) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) row[r] = s_px[(cy * 4 + r) * 16 + q * 4 + cx];
+            for (int r = 0; r < 4; r++) row[r] = s_px[(cy * 4 + r) * 16 + q * 4 + cx];
+        }
         // ---- histogram of the tile's valid pixels, right-most mode (FindAndRemoveMostUsedColor, :8335-8356) --------
         if (valid) {
 #pragma unroll
@@ -335,9 +368,13 @@ int yk_range1d_encode(yk_ctx* c) {
         hipLaunchKernelGGL(yk_r1_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bT, bP, (int)nb, tot);
         { int rc = yk_stage_end(c, YK_STAGE_RANGE1D_PACK); if (rc) return rc; }
         { int rc = yk_stage_begin(c, YK_STAGE_RANGE1D); if (rc) return rc; }
-        R1Direct D; D.offInBlk = cT; D.blockT = bT; D.blockP = bP; D.totals = tot; D.pixOut = c->r1Pix; D.typeOut = c->r1Type;
-        hipLaunchKernelGGL(yk_range1d_kernel<true>, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
-                           c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, (uint8_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, -1, D);
+        R1Direct D; D.offInBlk = cT; D.blockT = bT; D.blockP = bP; D.totals = tot; D.pixOut = c->r1Pix; D.typeOut = c->r1Type; D.pixCache = c->pixCache;
+        if (c->pixCacheValid && c->pixCache)                                  // the fused kernel left the uncovered cells' pixels: 4 B per pixel instead of 12
+            hipLaunchKernelGGL((yk_range1d_kernel<true, true>), dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                               c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, (uint8_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, -1, D);
+        else
+            hipLaunchKernelGGL(yk_range1d_kernel<true>, dim3(nStrips), dim3(64), 0, c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems,
+                               c->fullW, c->h, c->coverage, c->mtW, c->tilesW, T8, (uint8_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, -1, D);
         YK_HIP(c, hipGetLastError());
         { int rc = yk_stage_end(c, YK_STAGE_RANGE1D); if (rc) return rc; }
         // the totals stay on the device until a getter needs them (yk_range1d_finish): callers that keep frames in flight are not stopped here

@@ -341,6 +341,11 @@ int yk_launch_encode(yk_ctx* c, int rejectFactor, int mode3BitOnly, int wantDst,
         P.oBm0b += (uint32_t)(c->curFrame * c->fs.bm0b); P.oCov += (uint32_t)(c->curFrame * c->fs.coverage * 2);
         P.oInfo += (uint32_t)(c->curFrame * c->fs.tileInfo * 8); P.oRun += (uint32_t)(c->curFrame * c->fs.runSums * 4);
     }
+    P.pixCache = nullptr; c->pixCacheValid = false;
+    if (c->pixCacheOn && !batch && c->kernelVersion == 2 && c->nFrames == 1) {
+        if (!c->pixCache) YK_HIP(c, hipMalloc(&c->pixCache, (size_t)P.xBB64 * 64 * ((size_t)(c->h + 15) / 16 * 16) * 4 + 4096));
+        P.pixCache = c->pixCache; c->pixCacheValid = true;
+    }
     if (c->kernelVersion == 2) return yk_launch_encode2(c, P);
     // version 1 = the cross-check implementation of the test suite (tests/csrc/yk_encode_v1.hip), registered at run time
     if (batch) return yk_fail(c, YK_ERR_STATE, "batches need kernel version 2");

@@ -140,6 +140,11 @@ class HipTileEncoder:
         (device-side wait; see yk_order_fused_after)."""
         _chk(self._h, self._L.yk_order_fused_after(self._h, other._h))
 
+    def set_pixel_cache(self, on: bool = True):
+        """From the next encode() on, the fused kernel leaves the packed pixels of the cells it did not cover for the live 1-D path
+        (dynamic_tile_compressor), which then reads 4 B per pixel from there instead of 12 B from the planes (yk_set_pixel_cache)."""
+        _chk(self._h, self._L.yk_set_pixel_cache(self._h, 1 if on else 0))
+
     def select_frame(self, f: int):
         _chk(self._h, self._L.yk_select_frame(self._h, f))
 

@@ -46,6 +46,9 @@ bool EncoderContext::SetImageToEncode(Image* newImage) {
     bound = alphaDone = encoded = oneDReady = false; nextPass = 0;
     if (!original) return false;
     if (!ctx && yk_create(device, &ctx) != YK_OK) return fail("no usable HIP device (this path has no CPU fallback)");
+    // Convert() always runs the live 1-D path behind the gradient passes (:9451-9465): let the fused kernel leave it the uncovered cells' pixels,
+    // so that the planes are read from HBM once on the whole path
+    yk_set_pixel_cache(ctx, 1);
     const int w = original->GetWidth(), h = original->GetHeight(), n = original->HasAlpha() ? 4 : 3;
     if (yk_set_image(ctx, w, h, n, 0, h, 0) != YK_OK) return fail("yk_set_image");
     const int32_t* p[4] = { nullptr, nullptr, nullptr, nullptr };
