@@ -319,7 +319,7 @@ int yk_decode_1d_device(yk_ctx* c, const uint8_t* devType, size_t typeBytes, con
 int yk_decode_mask(yk_ctx* c, const uint8_t* bits, int tileBBoxW, int tileBBoxH, uint8_t* hostOut, size_t cap);
 /* 8x8-tiled u8 planes exactly as YAIK_SCustomDataSource hands them to imageBuilderFunc (include/YAIK.h:205-224) */
 int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, size_t capEach);
-const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize);
+const uint8_t* yk_decode_planes_device(yk_ctx* c, size_t* planeSize);
 /* internal_imageBuilderFunc (decoder/YAIK_DefaultCallback.cpp:24-191): de-tile into interleaved rows at outputImageStride.
  * Only the pixel bytes of a row are written; the rest of each outputImageStride-sized row is left untouched, like the reference
  * (include/YAIK.h:190: the stride places the image inside a larger user buffer).

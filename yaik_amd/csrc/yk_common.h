@@ -138,6 +138,7 @@ struct yk_ctx {
     uint8_t* dScratch = nullptr; size_t dScratchBytes = 0;
     uint8_t* dLoaded = nullptr;         // lattice point already popped from a colour stream (mapRGBMask)
     bool dSplit = false;
+    bool dPlanesStale = false;          // the planes were not cleared for this image: cells tile4x4Mask does not mark hold the previous image (yk_dec_settle)
     // timing
     // timing events: a ring of YK_EV_RING sets {alpha begin, alpha end, encode begin, encode end, pack end} so that a caller can
     // run many frames back to back and read the per-kernel averages afterwards without synchronising every frame

@@ -84,20 +84,32 @@ __global__ __launch_bounds__(1024) void yk_dec_corner_kernel(const uint32_t* __r
 // One workgroup per bitmap word.  The word's tiles are listed in LDS and the (tile, channel, row, run) items are spread over all 256
 // threads, so small tiles keep the workgroup as busy as large ones.  A thread produces a run of min(TX, 8) pixels of one row
 // and channel: in the 8x8-tiled plane layout that run is contiguous and leaves as ONE 8-byte (or 4-byte) store.
-struct DRenderLds { int xy[32][2]; uint8_t c[32][3][4]; };
-__device__ __forceinline__ void yk_dec_render_word(DRenderLds& L, const size_t wi, const uint32_t bits, const DPassGeo& g, int w, int h, int latW,
-                                                   const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
-                                                   uint32_t* __restrict__ tile4, int stride4) {
+#ifndef YK_DEC_ROWPAIR
+#define YK_DEC_ROWPAIR 0                                                     // 1: two rows per item (16-byte stores) for tiles 8 or 16 pixels wide -- measured slower (105 against 97 us at 8192 x 8192)
+#endif
+template <int NW> struct DRenderLdsN { int xy[32 * NW][2]; uint8_t c[32 * NW][3][4]; };
+typedef DRenderLdsN<1> DRenderLds;
+// the tiles of NW bitmap words (word k: index wi[k], bits bits[k]) of one pass, rendered together by the whole workgroup (256 threads)
+template <int NW>
+__device__ __forceinline__ void yk_dec_render_words(DRenderLdsN<NW>& L, const uint32_t* wi, const uint32_t* bitsN, const DPassGeo& g, int w, int h, int latW,
+                                                    const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                    uint32_t* __restrict__ tile4, int stride4) {
     const int TX = 1 << g.sx, TY = 1 << g.sy, dx = TX >> 2, dy = TY >> 2;
     const int lgGpr = g.sx > 3 ? g.sx - 3 : 0, lgPer = g.sy + lgGpr;            // runs per row, runs per channel (powers of two)
     const int GW = TX < 8 ? TX : 8, gpr = 1 << lgGpr, perCh = 1 << lgPer, nEl = 3 * perCh, sh = g.sx + g.sy;
-    if (threadIdx.x < 32 && ((bits >> threadIdx.x) & 1u)) {
-        int x, y; yk_dtile_from_bit(g, (uint32_t)(wi * 32 + threadIdx.x), x, y);
-        const int k = __popc(bits & ((1u << threadIdx.x) - 1u));
-        L.xy[k][0] = (x + TX > w || y + TY > h) ? -1 : x; L.xy[k][1] = y;
+    int nT = 0;
+    {
+        const int wk = threadIdx.x >> 5, bit = threadIdx.x & 31;
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) { const int pc = __popc(bitsN[k]); before += (k < wk) ? pc : 0; nT += pc; }
+        if (wk < NW && ((bitsN[wk] >> bit) & 1u)) {
+            int x, y; yk_dtile_from_bit(g, wi[wk] * 32u + (uint32_t)bit, x, y);
+            const int k = before + __popc(bitsN[wk] & ((1u << bit) - 1u));
+            L.xy[k][0] = (x + TX > w || y + TY > h) ? -1 : x; L.xy[k][1] = y;
+        }
     }
     __syncthreads();
-    const int nT = __popc(bits);
     // the four corner colours of the word's tiles, once (every run of a tile used to fetch them again: 4 byte loads per 8-byte store)
     for (int i = threadIdx.x; i < nT * 12; i += 256) {
         const int k = i / 12, e = i - 12 * k, c = e >> 2, q = e & 3;
@@ -107,25 +119,53 @@ __device__ __forceinline__ void yk_dec_render_word(DRenderLds& L, const size_t w
         L.c[k][c][q] = mapRGB[li * 3 + c];
     }
     __syncthreads();
-    for (int item = threadIdx.x; item < nT * nEl; item += 256) {
-        const int ck = item >> lgPer, k = ck / 3, c = ck - 3 * k;               // tile of the word, channel
-        const int x = L.xy[k][0], y = L.xy[k][1];
-        if (x < 0) continue;
-        const int r = item & (perCh - 1), ty = r >> lgGpr, gx = (r & (gpr - 1)) * GW;
-        const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&L.c[k][c][0]);
-        const int TL = c4 & 255, TR = (c4 >> 8) & 255, BL = (c4 >> 16) & 255, BR = c4 >> 24;
-        const int Lf = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
-        int v = Lf * (TX - gx) + R * gx;                                        // numerator at the first pixel of the run, + (R - L) per pixel
-        const int xx = x + gx, yy = y + ty;
-        uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7);
-        uint32_t lo = 0, hi = 0;
+    if (GW == 8 && YK_DEC_ROWPAIR) {
+        // tiles at least 8 pixels wide: an item = two rows of an 8-pixel run = 16 contiguous bytes of the 8x8-tiled plane (row pitch 8 inside a tile)
+        const int nEl2 = nEl >> 1, lgPer2 = lgPer - 1;
+        for (int item = threadIdx.x; item < nT * nEl2; item += 256) {
+            const int ck = item >> lgPer2, k = ck / 3, c = ck - 3 * k;           // tile of the list, channel
+            const int x = L.xy[k][0], y = L.xy[k][1];
+            if (x < 0) continue;
+            const int r = item & ((perCh >> 1) - 1), ty = (r >> lgGpr) * 2, gx = (r & (gpr - 1)) * 8;
+            const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&L.c[k][c][0]);
+            const int TL = c4 & 255, TR = (c4 >> 8) & 255, BL = c4 >> 16 & 255, BR = c4 >> 24;
+            const int xx = x + gx, yy = y + ty;
+            uint32_t o4[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
-        if (GW == 8) {
+            for (int rr = 0; rr < 2; rr++) {
+                const int Lf = TL * (TY - ty - rr) + BL * (ty + rr), R = TR * (TY - ty - rr) + BR * (ty + rr);
+                int v = Lf * (TX - gx) + R * gx;                                  // numerator at the first pixel of the run, + (R - L) per pixel
+                uint32_t lo = 0, hi = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
-            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
-        } else *reinterpret_cast<uint32_t*>(o) = lo;
+                for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
+                o4[rr * 2] = lo; o4[rr * 2 + 1] = hi;
+            }
+            uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8;
+            *reinterpret_cast<uint4*>(o) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        }
+    } else {
+        for (int item = threadIdx.x; item < nT * nEl; item += 256) {
+            const int ck = item >> lgPer, k = ck / 3, c = ck - 3 * k;           // tile of the list, channel
+            const int x = L.xy[k][0], y = L.xy[k][1];
+            if (x < 0) continue;
+            const int r = item & (perCh - 1), ty = r >> lgGpr, gx = (r & (gpr - 1)) * GW;
+            const uint32_t c4 = *reinterpret_cast<const uint32_t*>(&L.c[k][c][0]);
+            const int TL = c4 & 255, TR = (c4 >> 8) & 255, BL = (c4 >> 16) & 255, BR = c4 >> 24;
+            const int Lf = TL * (TY - ty) + BL * ty, R = TR * (TY - ty) + BR * ty;
+            int v = Lf * (TX - gx) + R * gx;                                    // numerator at the first pixel of the run, + (R - L) per pixel
+            const int xx = x + gx, yy = y + ty;
+            uint8_t* o = planes + (size_t)c * planeSize + ((size_t)(yy >> 3) * tileW + (xx >> 3)) * 64 + (yy & 7) * 8 + (xx & 7);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { lo |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
+            if (GW == 8) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { hi |= (uint32_t)((v >> sh) & 255) << (8 * i); v += R - Lf; }
+                *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+            } else *reinterpret_cast<uint32_t*>(o) = lo;
+        }
     }
     // cell (cx,cy) -> byte (cx>>2) + (cy>>1)*stride4, bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)   (e.g. YAIK_Gradient.cpp:951-953).  A tile's
     // cells lie in at most two mask bytes (one per pair of cell rows; tiles are at most 4 cells wide and aligned to their size): one
@@ -140,8 +180,14 @@ __device__ __forceinline__ void yk_dec_render_word(DRenderLds& L, const size_t w
         for (int cy = max(cy0, br * 2); cy < min(cy0 + dy, br * 2 + 2); cy++)
             for (int cx = cx0; cx < cx0 + dx; cx++) m |= 1u << ((((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
         const size_t byteIdx = (size_t)(cx0 >> 2) + (size_t)br * stride4;
-        atomicOr(&tile4[byteIdx >> 2], m << (8 * (byteIdx & 3)));
+        atomicOr(&tile4[byteIdx >> 2], m << (8 * (byteIdx & 3)));      // (collecting a 64x64 block's marks in LDS and merging them with eight atomics was slower: 105 against 97 us)
     }
+}
+__device__ __forceinline__ void yk_dec_render_word(DRenderLds& L, const size_t wi, const uint32_t bits, const DPassGeo& g, int w, int h, int latW,
+                                                   const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes, size_t planeSize, int tileW,
+                                                   uint32_t* __restrict__ tile4, int stride4) {
+    const uint32_t wi1[1] = { (uint32_t)wi }, b1[1] = { bits };
+    yk_dec_render_words<1>(L, wi1, b1, g, w, h, latW, mapRGB, planes, planeSize, tileW, tile4, stride4);
 }
 
 __global__ __launch_bounds__(256) void yk_dec_render_kernel(const uint32_t* __restrict__ bitmap, size_t nWords, DPassGeo g, int w, int h, int latW,
@@ -360,6 +406,53 @@ __global__ __launch_bounds__(256) void yk_decall_render_kernel(const uint8_t* __
     }
 }
 
+// ONE render launch for all passes: a workgroup owns a 64x64 block of the image and walks the passes in call order, rendering the tiles of the
+// bitmap words that cover its block (every tile shape's swizzle blocks are 64 or 32 pixels wide and high: at most 20.5 words per block and frame).
+// A later, overlapping tile still overwrites an earlier one like the reference (same workgroup, passes in order, stores of a pass acknowledged
+// before the next one starts); no lists of non-empty words are needed (an empty block costs its workgroup seven small loads), and seven dependent
+// launches of 16 us each (0.11 ms of the 0.33 ms decode of an 8192 x 8192 frame) become one.
+__global__ __launch_bounds__(256) void yk_decall_render_blocks_kernel(const DecPlan pl, int w, int h, int latW, const uint8_t* __restrict__ mapRGB, uint8_t* __restrict__ planes,
+                                                                      size_t planeSize, int tileW, uint32_t* __restrict__ tile4, int stride4) {
+    __shared__ DRenderLdsN<8> L;
+    __shared__ uint32_t s_word[7][8], s_idx[7][8];
+    const int xB64 = (w + 63) >> 6;
+    const int bx64 = (int)(blockIdx.x % (unsigned)xB64), by64 = (int)(blockIdx.x / (unsigned)xB64);
+    // the (up to 8) words of every pass that cover this block, fetched together: thread = pass * 8 + slot
+    if (threadIdx.x < 56) {
+        const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
+        uint32_t bits = 0, wi = 0;
+        if (p < pl.n) {
+            const DPassGeo g = yk_dpass_geo(pl.sx[p], pl.sy[p], w);
+            const int nbx = 64 / g.bigX, nby = 64 / g.bigY, wpb = g.bitCount >= 32 ? g.bitCount >> 5 : 1;      // swizzle blocks per 64x64 block, words per swizzle block
+            const int sb = k / wpb, wk = k - sb * wpb;
+            if (sb < nbx * nby) {
+                const int sbx = bx64 * nbx + (sb % nbx), sby = by64 * nby + (sb / nbx), yBB = (h + g.bigY - 1) / g.bigY;
+                if (sbx < g.xBB && sby < yBB) {
+                    const uint32_t bit0 = (uint32_t)(sby * g.xBB + sbx) * (uint32_t)g.bitCount;
+                    wi = (bit0 >> 5) + (uint32_t)wk;
+                    const uint32_t b0 = wi * 4u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (b0 + j < pl.nBytes[p]) bits |= (uint32_t)pl.bm[p][b0 + j] << (8 * j);
+                    if (g.bitCount < 32) bits &= 0xFFFFu << (bit0 & 31u);        // 16x16: two blocks share a word
+                }
+            }
+        }
+        s_word[p][k] = bits; s_idx[p][k] = wi;
+    }
+    __syncthreads();
+    bool wrote = false;
+    for (int p = 0; p < pl.n; p++) {
+        uint32_t bits8[8], idx8[8], any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { bits8[k] = s_word[p][k]; idx8[k] = s_idx[p][k]; any |= bits8[k]; }
+        if (!any) continue;                                                       // uniform over the workgroup
+        if (wrote) { __threadfence_block(); __syncthreads(); }                   // the previous pass's stores are out and its LDS image is free
+        const DPassGeo g = yk_dpass_geo(pl.sx[p], pl.sy[p], w);
+        yk_dec_render_words<8>(L, idx8, bits8, g, w, h, latW, mapRGB, planes, planeSize, tileW, tile4, stride4);
+        wrote = true;
+    }
+}
+
 // ---- partial planes: DecompressGradient4x4R / G / B / RG / GB / RB (decoder/YAIK_Gradient.cpp:1208-1226, :1420-2732) ------------
 // `loaded` holds one bit per plane and lattice point (the three planes of mapRGBMask); the masks are split first (UpdateTileAndRGBMask).
 __global__ void yk_dec_split_kernel(uint8_t* __restrict__ loaded, size_t lat, uint8_t* __restrict__ tile4, size_t tile4Size) {
@@ -526,7 +619,7 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
         const size_t i = ((size_t)blockIdx.x * YK_D1_TPL + rep) * 64 + (threadIdx.x >> 2);
         ow[rep] = i < T8 ? offInBlk[i] : 0xF0000000u;                           // past the end: a tile with nothing to decode
     }
-    int tb[YK_D1_TPL]; uint4 L[YK_D1_TPL]; bool coded[YK_D1_TPL];
+    int tb[YK_D1_TPL]; uint4 L[YK_D1_TPL]; bool coded[YK_D1_TPL], live[YK_D1_TPL];
 #pragma unroll
     for (int rep = 0; rep < YK_D1_TPL; rep++) {
         const int q = (int)(ow[rep] >> 28);
@@ -538,7 +631,8 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
         const int nTop = 2 - (q & 1) - ((q >> 1) & 1);
         const size_t to = (baseT + offT) * 3;
         // the tile's three parameter bytes: one byte load per lane (lane j of the tile fetches byte min(j, 2)), handed round the quad by DPP below
-        coded[rep] = q != 0xF && to + 2 < typeBytes;
+        live[rep] = q != 0xF;                                                     // the tile has a quadrant nothing filled: it is written here, with zeros when its parameters are missing
+        coded[rep] = live[rep] && to + 2 < typeBytes;
         tb[rep] = 0;
         if (coded[rep]) tb[rep] = type[to + (j < 2 ? j : 2)];
         L[rep] = make_uint4(0u, 0u, 0u, 0u);
@@ -559,7 +653,9 @@ __global__ __launch_bounds__(256) void yk_dec1d_kernel(const uint32_t* __restric
         const int qh = (q >> (half * 2)) & 3;
         const int color0 = __builtin_amdgcn_update_dpp(0, tb[rep], 0x00, 0xF, 0xF, true), base = __builtin_amdgcn_update_dpp(0, tb[rep], 0x55, 0xF, 0xF, true),
                   delta = __builtin_amdgcn_update_dpp(0, tb[rep], 0xAA, 0xF, 0xF, true);
-        if (qh == 3 || !coded[rep]) continue;
+        // a tile the stream does not reach decodes as color0 = 0 with every index 0: zeros.  (The planes are not cleared per frame any more: what no
+        // gradient / LUT tile covered is written here, whatever the stream holds: yk_decode_begin.)
+        if (qh == 3 || !live[rep]) continue;
         const int delta2 = ((delta * invRange) >> 8) + 1;                       // :66, :86
         // v = L ? base + (((L - 1) * delta2) >> 16) : color0 (:113-124), four pixels of a dword at a time: for L >= 1 the value is byte 2 of
         // K + L * delta2 with K = (base << 16) - delta2 (delta2 < 2^21, L a byte: a 24-bit multiply with the byte selected by the instruction);
@@ -652,6 +748,34 @@ static int yk_dec_scratch(yk_ctx* c, size_t bytes) {
 
 extern "C" {
 
+// zero every 4x4 cell tile4x4Mask does not mark (thread = 8x8 tile and plane; the mask is shared by the planes until a plane-subset pass splits it)
+__global__ __launch_bounds__(256) void yk_dec_zero_unmarked_kernel(const uint8_t* __restrict__ tile4, size_t tile4Size, int split, int stride4, int tilesW, size_t T8,
+                                                                   uint8_t* __restrict__ planes, size_t planeSize) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= T8) return;
+    const int tx = (int)(i % (size_t)tilesW), ty = (int)(i / (size_t)tilesW);
+    const uint8_t m = tile4[(split ? (size_t)p * tile4Size : 0) + (size_t)(tx >> 1) + (size_t)ty * stride4];     // byte = 16x8 pixels: bit ((cx>>1)&1)*4 + (cy&1)*2 + (cx&1)
+    const int sh = (tx & 1) * 4;
+    uint8_t* o = planes + (size_t)p * planeSize + i * 64;
+#pragma unroll
+    for (int qy = 0; qy < 2; qy++)
+#pragma unroll
+        for (int qx = 0; qx < 2; qx++)
+            if (!((m >> (sh + qy * 2 + qx)) & 1))
+                for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(o + (qy * 4 + r) * 8 + qx * 4) = 0u;
+}
+static int yk_dec_settle(yk_ctx* c) {
+    if (!c->dPlanesStale) return YK_OK;
+    const int w = c->dw, h = c->dh;
+    const size_t T8 = (size_t)(w >> 3) * (h >> 3);
+    hipLaunchKernelGGL(yk_dec_zero_unmarked_kernel, dim3((unsigned)((T8 + 255) / 256), 3), dim3(256), 0, c->stream, c->dTile4, c->dTile4Size, c->dSplit ? 1 : 0,
+                       (w + 15) >> 4, w >> 3, T8, c->dPlanes, c->dPlaneSize);
+    YK_HIP(c, hipGetLastError());
+    c->dPlanesStale = false;
+    return YK_OK;
+}
+
 int yk_decode_begin(yk_ctx* c, int w, int h) {
     if (!c) return YK_ERR_BAD_ARG;
     if (w < 16 || h < 16 || (w & 15) || (h & 15) || w > 32752 || h > 32752) return yk_fail(c, YK_ERR_BAD_ARG, "decode needs width/height multiples of 16");
@@ -672,7 +796,10 @@ int yk_decode_begin(yk_ctx* c, int w, int h) {
         YK_HIP(c, hipMalloc(&c->dLoaded, lat));
         YK_HIP(c, hipMalloc(&c->dTile4, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4));   // three planes once the masks are split
     }
-    YK_HIP(c, hipMemsetAsync(c->dPlanes, 0, c->dPlaneSize * 3, c->stream));
+    // The planes (3 B per pixel: 201 MB at 8192 x 8192, 40 us of every frame) are NOT cleared: every renderer marks what it writes in tile4x4Mask and
+    // the 1-D decode writes every unmarked quadrant, so after a whole file nothing stale is left; a flow that stops earlier (or writes without
+    // marking: the plane-subset loops) gets the unmarked cells zeroed when it needs them (yk_dec_settle).
+    c->dPlanesStale = true;
     YK_HIP(c, hipMemsetAsync(c->dMapRGB, 0, lat * 3, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dLoaded, 0, lat, c->stream));
     YK_HIP(c, hipMemsetAsync(c->dTile4, 0, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4, c->stream));
@@ -797,13 +924,9 @@ int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX,
     hipLaunchKernelGGL(yk_decall_scan_kernel, dim3(1), dim3(1024), 0, c->stream, blockSums, blockWords, pl, passWords);
     hipLaunchKernelGGL(yk_decall_stream_kernel<true>, dim3((unsigned)nbTot), dim3(1024), 0, c->stream, pl, w, h, latW, c->dLoaded, c->dLatticeOwner, blockSums, blockWords,
                        perThread, c->dMapRGB, wordList, factor);
-    for (int p = 0; p < nPasses; p++) {                                      // in call order: a later, overlapping tile overwrites an earlier one like the reference
-        const DPassGeo g = yk_dpass_geo(pl.sx[p], pl.sy[p], w);
-        const size_t words = (pl.nBytes[p] + 3) / 4;
-        const unsigned grid = (unsigned)(words < 8192 ? (words ? words : 1) : 8192);
-        hipLaunchKernelGGL(yk_decall_render_kernel, dim3(grid), dim3(256), 0, c->stream, pl.bm[p], pl.nBytes[p], wordList + pl.wordStart[p], passWords + p, g, w, h, latW,
-                           c->dMapRGB, c->dPlanes, c->dPlaneSize, w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
-    }
+    // one render launch: a workgroup per 64x64 block of the image walks the passes in call order
+    hipLaunchKernelGGL(yk_decall_render_blocks_kernel, dim3((unsigned)(((w + 63) / 64) * ((h + 63) / 64))), dim3(256), 0, c->stream, pl, w, h, latW,
+                       c->dMapRGB, c->dPlanes, c->dPlaneSize, w >> 3, reinterpret_cast<uint32_t*>(c->dTile4), (w + 15) >> 4);
     YK_HIP(c, hipGetLastError());
     { int rc2 = yk_stage_end(c, YK_STAGE_DEC_GRADIENT); if (rc2) return rc2; }
     return YK_OK;
@@ -831,6 +954,7 @@ int yk_decode_gradient_planes(yk_ctx* c, int planeBit, int consistentMarks, cons
     if (planeBit < 1 || planeBit > 6) return yk_fail(c, YK_ERR_BAD_ARG, "planeBit must be 1..7");
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
     YK_HIP(c, hipSetDevice(c->device));
+    { const int rcs = yk_dec_settle(c); if (rcs) return rcs; }               // the plane-subset loops write without marking (reference behaviour): from here on the planes are fully defined
     const int w = c->dw, h = c->dh, latW = w / 4 + 1;
     const size_t lat = (size_t)latW * (h / 4 + 1);
     const size_t need = ((size_t)((w + 31) / 32) * ((h + 31) / 32) * 64) >> 3;
@@ -908,6 +1032,7 @@ static int yk_decode_1d_impl(yk_ctx* c, const uint8_t* typeStream, size_t typeBy
     }
     YK_HIP(c, hipGetLastError());
     { int rc2 = yk_stage_end(c, YK_STAGE_DEC_1D); if (rc2) return rc2; }
+    c->dPlanesStale = false;                                                 // every unmarked quadrant of every plane has been written
     if (!onDevice) YK_HIP(c, hipStreamSynchronize(c->stream));
     return YK_OK;
 }
@@ -940,6 +1065,7 @@ int yk_decode_planes(yk_ctx* c, uint8_t* hostR, uint8_t* hostG, uint8_t* hostB, 
     if (!c->dPlanes) return yk_fail(c, YK_ERR_STATE, "yk_decode_begin first");
     if (capEach < c->dPlaneSize) return yk_fail(c, YK_ERR_RANGE, "plane buffer too small");
     YK_HIP(c, hipSetDevice(c->device));
+    { const int rcs = yk_dec_settle(c); if (rcs) return rcs; }
     uint8_t* dst[3] = { hostR, hostG, hostB };
     for (int p = 0; p < 3; p++) YK_HIP(c, hipMemcpyAsync(dst[p], c->dPlanes + p * c->dPlaneSize, c->dPlaneSize, hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
@@ -959,6 +1085,7 @@ static int yk_decode_output_impl(yk_ctx* c, uint8_t* hostOut, size_t outputImage
     const size_t dPitch = (rowBytes + 15) & ~(size_t)15;
     const size_t outBytes = dPitch * h, aBytes = hostAlpha ? (size_t)strideA * h : 0, oA = (outBytes + 31) & ~(size_t)15;
     int rc = yk_dec_scratch(c, oA + aBytes + 64); if (rc) return rc;
+    rc = yk_dec_settle(c); if (rc) return rc;
     if (hostAlpha) YK_HIP(c, hipMemcpyAsync(c->dScratch + oA, hostAlpha, aBytes, hipMemcpyHostToDevice, c->stream));
     { int rc2 = yk_stage_begin(c, YK_STAGE_DEC_DETILE); if (rc2) return rc2; }
     hipLaunchKernelGGL(yk_dec_detile_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, c->stream, c->dPlanes, c->dPlaneSize, w >> 3, w, h,
@@ -982,8 +1109,9 @@ int yk_decode_output_reference_rgba(yk_ctx* c, uint8_t* hostOut, size_t outputIm
     return yk_decode_output_impl(c, hostOut, outputImageStride, hostAlpha, strideA, true);
 }
 
-const uint8_t* yk_decode_planes_device(const yk_ctx* c, size_t* planeSize) {
+const uint8_t* yk_decode_planes_device(yk_ctx* c, size_t* planeSize) {
     if (!c || !c->dPlanes) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || yk_dec_settle(c) != YK_OK) return nullptr;
     if (planeSize) *planeSize = c->dPlaneSize;
     return c->dPlanes;
 }
