@@ -72,6 +72,11 @@ int yk_set_image(yk_ctx* c, int fullW, int fullH, int nPlanes, int y0, int h, in
 int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideElems);
 /* zero-copy: planes already resident in HBM */
 int yk_bind_device_planes(yk_ctx* c, const int32_t* const devPlanes[4], int strideElems);
+/* The path is defined for samples in 0..255 held in int32 planes (the fused kernel keeps their low byte; the reference reads the whole int,
+ * encoder/framework.h:116-121).  yk_upload_planes checks what it copied and fails with YK_ERR_BAD_ARG (no planes bound afterwards) when a sample
+ * lies outside; callers that bind device memory and cannot vouch for its contents call yk_validate_planes: *nOutOfRange = samples outside 0..255
+ * in the bound planes (all frames of a batch; one streaming pass, synchronises). */
+int yk_validate_planes(yk_ctx* c, size_t* nOutOfRange);
 
 /* ---- a9  alpha tile-reject:  EncoderContext::MipPrefilter (EncoderContext.cpp:1257-1427) -----
  * stage 1 (per stripe): per aligned 16x16 block "all 256 alphas == 0" + bounding box of kept blocks. */
@@ -263,6 +268,10 @@ void yk_comm_destroy(void* comm);
 /* Rank side (one process per GPU): every rank but `root` sends sendBytes from devSend; the root receives recvBytes[r] bytes of rank r at
  * devRecv + recvOffsets[r] (its own payload is copied there on the device; recvBytes / recvOffsets / devRecv may be NULL elsewhere).
  * Sender and root must name the same count for a rank: derive it on both sides from that rank's previous header. */
+/* COUNTS MUST AGREE: rank r's sendBytes has to equal recvBytes[r] as the root posts it.  The library cannot check this across ranks, and an
+ * ncclSend / ncclRecv pair with different counts is undefined in RCCL (a hang or a truncated payload).  Callers either exchange the sizes first
+ * or use a fixed capacity per rank with the true length inside the payload (the framed export's 128-byte header carries it; that is what
+ * yaik_amd/distributed.py and EncoderContext::ConvertHotPathStripes do). */
 int  yk_gather_maps(yk_ctx* c, void* comm, int root, const void* devSend, size_t sendBytes,
                     void* devRecv, const size_t* recvBytes, const size_t* recvOffsets);
 /* One process driving n devices: rank r's sendBytes[r] bytes land at devRecv + recvOffsets[r] on the root's device. */
@@ -280,11 +289,16 @@ int yk_decode_gradient(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t*
 /* The same with both streams already in HBM on the handle's device (e.g. straight from an encoder handle: yk_gradient_bitmap_device,
  * yk_gradient_corners_device) and no host synchronisation.  remapRange > 0 applies PaletteFullRangeRemapping(range) to the colour stream on
  * the way in (decoder/YAIK_GenericFunctions.cpp:128-137; the encoder's streams are CompressF(.., 250) values), 0 takes it as it is. */
+/* ORDERING is the caller's: the yk_decode_*_device entry points read the given device memory on THIS handle's stream and nothing orders that
+ * stream behind the producer's.  When the streams come from an encoder handle (yk_gradient_corners_device, yk_range1d_streams_device,
+ * yk_gradient_bitmap_device), order the two first: yk_synchronize(producer) on the host, or a device-side wait (yk_stream_handoff(producer,
+ * consumerStream) / yk_stream_wait_for(c, producerStream) with the streams the caller gave the handles through yk_set_stream).  The pointers go
+ * stale with the producer's next encode / yk_set_image. */
 int yk_decode_gradient_device(yk_ctx* c, int tileShiftX, int tileShiftY, const uint8_t* devBitmap, size_t bitmapBytes,
                               const uint8_t* devRgb, size_t rgbBytes, int remapRange);
 /* All 'GTIL' chunks of a file at once, streams in HBM: the same result as yk_decode_gradient_device for pass 0 .. nPasses-1 in that order
- * (first toucher of every lattice point over ALL passes in one launch, one scan, one launch popping the colours, then one render per
- * pass from a list of its non-empty bitmap words: 11 launches for seven passes instead of 35 + 21 copies / clears).  Up to seven passes per
+ * (first toucher of every lattice point over ALL passes in one launch, one scan, one launch popping the colours, then ONE render launch
+ * in which a workgroup owns a 64x64 block of the image and walks the passes in call order: 5 launches for seven passes instead of 35 + 21 copies / clears).  Up to seven passes per
  * call and 2^25 tile slots per pass; beyond that the call runs the passes one after the other. */
 int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX, const int* tileShiftY, const uint8_t* const* devBitmap,
                                   const size_t* bitmapBytes, const uint8_t* const* devRgb, const size_t* rgbBytes, int remapRange);

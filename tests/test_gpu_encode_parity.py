@@ -122,3 +122,31 @@ def test_other_reject_factors_bit_exact(hip, oracle_built, rf):
             defs, nib, nn, dst = ora.dynamic_tile_encode(p, False)
             d2, n2, nn2 = hip.range_streams(p)
             assert nn2 == nn and np.array_equal(d2, defs) and np.array_equal(n2, nib), (rf, p)
+
+
+def test_samples_outside_0_255_are_refused():
+    """SURVEY 7 / include/yaik_hip.h: the path is defined for samples in 0..255 (the fused kernel keeps the low byte, the reference reads the whole
+    int, framework.h:116-121).  yk_upload_planes refuses host planes that break it (YK_ERR_BAD_ARG, nothing bound); planes bound in place are
+    checked on request."""
+    import torch
+    from yaik_amd._lib import YaikError
+    from yaik_amd.encoder import HipTileEncoder
+    planes = synth_planes(128, n_planes=3)
+    e = HipTileEncoder(0)
+    try:
+        e.set_image(planes)
+        assert e.validate_planes() == 0
+        bad = planes.copy()
+        bad[1, 17, 33] = 256
+        bad[2, 100, 5] = -1
+        with pytest.raises(YaikError, match="0..255"):
+            e.set_image(bad)
+        with pytest.raises(YaikError):
+            e.encode(3, False, False)                            # nothing is bound after the refusal
+        t = torch.from_numpy(bad).to("cuda").contiguous()
+        e.set_image(t)                                           # bound in place: the caller vouches for the contents ...
+        assert e.validate_planes() == 2                          # ... or asks
+        e.set_image(planes)
+        assert not compare_encode(planes, e, False)
+    finally:
+        e.close()

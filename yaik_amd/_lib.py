@@ -44,6 +44,7 @@ SIGNATURES = {
     "yk_set_image": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "yk_upload_planes": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
     "yk_bind_device_planes": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
+    "yk_validate_planes": (C.c_int, [vp, szp]),
     "yk_alpha_reject": (C.c_int, [vp]),
     "yk_get_stripe_bbox": (C.c_int, [vp, vp]),
     "yk_alpha_finish": (C.c_int, [vp, vp]),

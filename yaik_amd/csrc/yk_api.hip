@@ -6,6 +6,7 @@
 #endif
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 int yk_fail(yk_ctx* c, int code, const char* what, hipError_t e) {
@@ -115,9 +116,35 @@ static int yk_stage_fold(yk_ctx* c, int st) {               // waits for the rec
     c->stN[st] = 0;
     return YK_OK;
 }
+// the ring is full: account the intervals that have already completed (no host wait) and, if none has, drop the oldest one -- a caller that keeps
+// frames in flight is never stopped here (the averages of yk_stage_ms then miss that interval; callers that want every one query at most every
+// YK_STAGE_RING intervals)
+static int yk_stage_make_room(yk_ctx* c, int st) {
+    int kept = 0;
+    for (int k = 0; k < c->stN[st]; k++) {
+        hipEvent_t e0 = c->stEv[st][k][0], e1 = c->stEv[st][k][1];
+        if (hipEventQuery(e1) == hipSuccess) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, e0, e1) == hipSuccess) { c->stAcc[st] += t; c->stCalls[st]++; }
+        } else {
+            (void)hipGetLastError();                                          // hipErrorNotReady is not an error here
+            if (kept != k) { std::swap(c->stEv[st][kept][0], c->stEv[st][k][0]); std::swap(c->stEv[st][kept][1], c->stEv[st][k][1]); }
+            kept++;
+            continue;
+        }
+    }
+    if (kept == YK_STAGE_RING) {                                              // nothing has completed: the oldest interval is dropped
+        hipEvent_t d0 = c->stEv[st][0][0], d1 = c->stEv[st][0][1];
+        for (int k = 1; k < kept; k++) { c->stEv[st][k - 1][0] = c->stEv[st][k][0]; c->stEv[st][k - 1][1] = c->stEv[st][k][1]; }
+        c->stEv[st][kept - 1][0] = d0; c->stEv[st][kept - 1][1] = d1;
+        kept--;
+    }
+    c->stN[st] = kept;
+    return YK_OK;
+}
 int yk_stage_begin(yk_ctx* c, int st) {
     if (st < 0 || st >= YK_NUM_STAGES) return YK_ERR_BAD_ARG;
-    if (c->stN[st] == YK_STAGE_RING) { int rc = yk_stage_fold(c, st); if (rc) return rc; }
+    if (c->stN[st] == YK_STAGE_RING) { int rc = yk_stage_make_room(c, st); if (rc) return rc; }
     hipEvent_t* ev = c->stEv[st][c->stN[st]];
     for (int i = 0; i < 2; i++) if (!ev[i]) YK_HIP(c, hipEventCreate(&ev[i]));
     YK_HIP(c, hipEventRecord(ev[0], c->stream));
@@ -269,6 +296,46 @@ static int yk_check_planes(yk_ctx* c, const int32_t* const p[4], int strideElems
     return YK_OK;
 }
 
+// Precondition of the whole path (include/yaik_hip.h): plane samples lie in 0..255 -- the fused kernel keeps only their low byte, the
+// reference reads the full int (framework.h:116-121), so an out-of-range sample would silently give different tiles.  One streaming pass over the bound
+// planes (rows of this stripe incl. its halo) counts the samples outside; a workgroup adds its count with one atomic, and only when it has any.
+__global__ __launch_bounds__(256) void yk_validate_kernel(const int32_t* __restrict__ plane, int strideElems, int w, int rows, unsigned long long* __restrict__ bad) {
+    __shared__ unsigned s_bad;
+    if (threadIdx.x == 0) s_bad = 0u;
+    __syncthreads();
+    const int vecPerRow = w >> 2;
+    unsigned mine = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)vecPerRow * rows; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / vecPerRow), xv = (int)(i - (long long)y * vecPerRow);
+        const int4 v = *reinterpret_cast<const int4*>(plane + (size_t)y * strideElems + (size_t)xv * 4);
+        mine += ((v.x & ~255) ? 1u : 0u) + ((v.y & ~255) ? 1u : 0u) + ((v.z & ~255) ? 1u : 0u) + ((v.w & ~255) ? 1u : 0u);
+    }
+    if (mine) atomicAdd(&s_bad, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bad) atomicAdd(bad, (unsigned long long)s_bad);
+}
+
+int yk_validate_planes(yk_ctx* c, size_t* nOutOfRange) {
+    if (!c || !nOutOfRange) return YK_ERR_BAD_ARG;
+    if (!c->B.plane[0]) return yk_fail(c, YK_ERR_STATE, "bind planes first");
+    YK_HIP(c, hipSetDevice(c->device));
+    unsigned long long* dBad = nullptr;
+    YK_HIP(c, hipMalloc(&dBad, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dBad, 0, sizeof(unsigned long long), c->stream);
+    const int rows = c->h + c->halo;
+    for (int f = 0; f < c->nFrames && e == hipSuccess; f++)
+        for (int i = 0; i < c->nPlanes; i++)
+            hipLaunchKernelGGL(yk_validate_kernel, dim3(c->numCU * 8), dim3(256), 0, c->stream, c->B.plane[i] + (size_t)f * c->fs.plane, c->strideElems, c->fullW, rows, dBad);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, dBad, sizeof bad, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dBad);
+    if (e != hipSuccess) return yk_fail(c, YK_ERR_HIP, "yk_validate_planes", e);
+    *nOutOfRange = (size_t)bad;
+    return YK_OK;
+}
+
 int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideElems) {
     int rc = yk_check_planes(c, hostPlanes, strideElems); if (rc) return rc;
     YK_HIP(c, hipSetDevice(c->device));
@@ -288,6 +355,15 @@ int yk_upload_planes(yk_ctx* c, const int32_t* const hostPlanes[4], int strideEl
     c->fs.plane = 0; yk_rebase(c, 0);
     c->strideElems = c->fullW;
     c->encoded = false; c->alphaDone = false; c->alphaFinished = false; c->cornersReady = false; c->ppActive = false; c->ppLastBit = 0; c->previewFresh = false;
+    // the 0..255 precondition is enforced where the boundary hands over host planes (a streaming pass over what was just copied: ~0.2 ms next to
+    // ~48 ms of PCIe copy for an 8192 x 8192 RGBA image); callers that bind device memory check with yk_validate_planes when they cannot vouch for it
+    size_t bad = 0;
+    rc = yk_validate_planes(c, &bad); if (rc) return rc;
+    if (bad) {
+        for (int i = 0; i < 4; i++) c->B.plane[i] = nullptr;
+        yk_rebase(c, 0);
+        return yk_fail(c, YK_ERR_BAD_ARG, ("plane samples outside 0..255: " + std::to_string(bad) + " (the tile path is defined for 8-bit samples held in int32 planes)").c_str());
+    }
     return YK_OK;
 }
 

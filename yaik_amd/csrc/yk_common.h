@@ -58,6 +58,8 @@ struct YkEncodeParams {
     YkFrameStrides fs;
 };
 
+// The layout of yk_ctx must NOT depend on YK_TEST_HOOKS: the product library and the test-hooks build of the same sources are loaded side by
+// side by the tests, each owning the handles it created (yaik_amd/encoder.py keeps a handle with its library); no member below is conditional.
 struct yk_ctx {
     int device = -1;
     int numCU = 256;             // compute units of the device (persistent grids are sized from it)

@@ -17,9 +17,15 @@ from ._lib import YaikError, lib
 PASSES = [(4, 4), (4, 3), (3, 4), (3, 3), (3, 2), (2, 3), (2, 2)]   # EncoderContext.cpp:9057-9093
 
 
+# handle -> the library build that created it (the product library, or the test-hooks build of the same sources: tests/csrc/libyaik_hip_test.so):
+# a handle is only ever passed back to the build that owns it, error lookups included
+_HANDLE_LIB: dict = {}
+
+
 def _chk(h, rc: int, L=None):
     if rc != 0:
-        msg = (L or lib()).yk_last_error(h)
+        owner = L or _HANDLE_LIB.get(getattr(h, "value", h)) or lib()
+        msg = owner.yk_last_error(h)
         raise YaikError(f"yaik_hip error {rc}: {msg.decode() if msg else '?'}")
 
 
@@ -37,11 +43,13 @@ class HipTileEncoder:
         if rc != 0:
             raise YaikError(f"yk_create failed ({rc}): no usable HIP device -- the product path has no CPU fallback")
         self._h = h
+        _HANDLE_LIB[h.value] = L
         self._keepalive = None
         self.w = self.h = self.n = 0
 
     def close(self):
         if getattr(self, "_h", None):
+            _HANDLE_LIB.pop(self._h.value, None)
             self._L.yk_destroy(self._h)
             self._h = None
 
@@ -77,6 +85,12 @@ class HipTileEncoder:
             _chk(self._h, L.yk_upload_planes(self._h, ptrs, w))
             _chk(self._h, L.yk_synchronize(self._h))
         self._keepalive = planes
+
+    def validate_planes(self) -> int:
+        """Samples of the bound planes outside 0..255 (the precondition of the path; yk_upload_planes enforces it itself)."""
+        n = C.c_size_t(0)
+        _chk(self._h, self._L.yk_validate_planes(self._h, C.byref(n)))
+        return int(n.value)
 
     # ---- EncoderContext::MipPrefilter ---------------------------------------------------------------
     def alpha_reject(self):

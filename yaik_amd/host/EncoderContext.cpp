@@ -113,7 +113,7 @@ static bool copyPreview(yk_ctx* ctx, int pass, int planeBit, Image* testOutput, 
 int EncoderContext::FittingQuadSmooth(int rejectFactor, Plane* a, Plane* b, Plane* c, Image* testOutput, bool useYCoCg,
                                       int tileBitSizeX, int tileBitSizeY) {
     if (!bound) { fail("FittingQuadSmooth: SetImageToEncode first"); return 0; }
-    if (useYCoCg) { fail("FittingQuadSmooth: the YCoCg variant is not on this path"); return 0; }
+    (void)useYCoCg;      // ignored, like the reference: its only use (selecting YCoCgImg as the source) is commented out at EncoderContext.cpp:3727
     if ((a && a != original->GetPlane(0)) || (b && b != original->GetPlane(1)) || (c && c != original->GetPlane(2)) || (!a && !b && !c)) {
         fail("FittingQuadSmooth: srcA/B/C must be planes 0/1/2 of the image or NULL"); return 0;
     }

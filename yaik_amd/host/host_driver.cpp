@@ -271,7 +271,7 @@ int main(int argc, char** argv) {
     Image* preview = Image::CreateImage(w, h, 3, true);
     int counts[7];
     for (int i = 0; i < 7; i++) {
-        counts[i] = ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), preview, false, passes[i][0], passes[i][1]);
+        counts[i] = ctx->FittingQuadSmooth(3, img->GetPlane(0), img->GetPlane(1), img->GetPlane(2), preview, (i & 1) != 0 /* useYCoCg: ignored, like the reference (:3727) */, passes[i][0], passes[i][1]);
         blob(nm("grad_bitmap", i), ctx->LastGradientBitmap().data(), ctx->LastGradientBitmap().size());
         blob(nm("grad_rgbraw", i), ctx->LastGradientRGBStream().data(), ctx->LastGradientRGBStream().size());
     }

@@ -38,7 +38,9 @@ struct YAIK_SDecodedImage {
     bool             hasAlpha;                 // filled by YAIK_DecodeImagePre
     imageBuilderFunc customImageOutput;        // Pre installs the default builder; the user may replace it before YAIK_DecodeImage
     void*            userContextCustomImage;
-    YAIK_SMemAlloc   userMemoryAllocator;      // Pre installs malloc/free; the user may replace it
+    YAIK_SMemAlloc   userMemoryAllocator;      // Pre installs malloc/free; the user may replace it.  HOST memory of a decode only: the planes,
+                                                // corner lattice, masks and streams of this implementation live in HBM (hipMalloc, owned by the
+                                                // decode slot's device handle) and never come from this allocator
     uint8_t*         outputImage;              // user buffer, required by YAIK_DecodeImage
     int32_t          outputImageStride;
     bool             hasAlpha1Bit;
