@@ -846,7 +846,7 @@ def main() -> int:
     roof_torch = measured_copy_roof(dev)
     roof_copy, roof_read = measured_stream_roof(enc)
     roof = max(roof_copy, roof_read)
-    frame_ms = elapsed / args.steps / K * 1e3 if not BF else elapsed / args.steps / (K * BF) * 1e3
+    frame_ms = (W * W / 1e6) / (value / world) * 1e3                          # per GPU: what one frame costs at the measured whole-job rate
     frame_bytes = 16 * W * W + W * W // 256 // 8 + bitmap_bytes + out_bytes      # the four int32 planes once + every output of the frame
     # the same kernel with nothing else on the chip (after the timed region, rank 0, plain frames only): in the timed region above the other
     # frame's alpha kernel runs UNDER the fused kernel (that is what hides it) and stretches it by a few per cent
