@@ -17,7 +17,8 @@ extern "C" {
  * which = 2: the same shortcut for GetValueModel1's division, 0 <= n < 4096, 1 <= delta <= 255 (EncoderContext.cpp:8383-8391)
  * which = 3: the quantiser table of the fused kernel: for every (min, max) of a tile the LUTs of DynamicTile::buildTable
  *            (EncoderContext.cpp:625-699) equal BN + K[rangeDecode], and every value in [min, max] finds in the table the index
- *            and minDiff the first-minimum scan of GetTileDynamic_Y (:873-881) finds in those LUTs */
+ *            and minDiff the first-minimum scan of GetTileDynamic_Y (:873-881) finds in those LUTs
+ * which = 4: the 1-D range kernel's (v * A + B) >> 20 == GetValueModel1's byte for every (delta, minCol, v) (EncoderContext.cpp:8383-8391) */
 int yk_selftest(yk_ctx* c, int which, int* result);
 /* TIMING ONLY: ablation switches for profiling the fused kernel (results are WRONG while non-zero; default 0).
  * 1 = skip the range quantiser, 2 = skip the gradient passes, 4 = skip the nearest-entry lookups (table gathers; LUT search in

@@ -38,6 +38,14 @@ def test_reciprocal_model1_division_is_exact(hip):
     assert res.value == 0, f"{res.value} (n, delta) pairs differ from the integer division of GetValueModel1"
 
 
+def test_model1_multiply_shift_is_exact(hip):
+    """the 1-D range kernel codes a pixel as (v * A + B) >> 20 (yk_r1_magic): every delta, minCol and v against GetValueModel1's C expression"""
+    from yaik_amd._lib import test_lib as lib
+    res = C.c_int(-1)
+    assert lib().yk_selftest(hip._h, 4, C.byref(res)) == 0
+    assert res.value == 0, f"{res.value} (delta, minCol, v) triples differ from GetValueModel1"
+
+
 def test_quantiser_table_matches_lut_scan(hip):
     """yk_encode2_kernel reads index / minDiff of a pixel from a table indexed by (rangeDecode, v - BN): for every (min, max) of a
     tile the LUTs built the reference's way must equal BN + K[rangeDecode], and every value in [min, max] must find in the table

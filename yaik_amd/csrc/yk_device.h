@@ -57,3 +57,20 @@ __device__ __forceinline__ float yk_div_exact(float n, float d, float r) {
     const float e = __fmaf_rn(-q0, d, n);
     return __fmaf_rn(e, r, q0);
 }
+
+// GetValueModel1 (encoder/EncoderContext.cpp:8383-8391) without a division per pixel: a coded pixel's byte is
+//     1 + trunc(((v - minCol) * 15 + (delta >> 1) - 1) / delta)  =  floor((n + delta) / delta),  n + delta >= 0 for every delta >= 1,
+// and floor(x / delta) == (x * M) >> 20 with M = floor(2^20 / delta) + 1 for every x the path can produce (x <= 16.5 delta <= 4207: the
+// error term x * (M * delta - 2^20) stays below 2^20; exhaustive over delta and v - minCol: yk_selftest 4).  Folded into ONE 24-bit
+// multiply-add per pixel: byte = (v * A + B) >> 20 with A = 15 M < 2^24 and B = ((delta >> 1) - 1 + delta - 15 minCol) * M mod 2^32.
+// delta == 0 (one value left besides color0 +- 1): every coded pixel is 1.
+__device__ __forceinline__ void yk_r1_magic(int delta, int minCol, uint32_t* A, uint32_t* B) {
+    if (delta == 0) { *A = 0u; *B = 1u << 20; return; }
+    int m = __float2int_rz(1048576.0f * __builtin_amdgcn_rcpf((float)delta));     // floor(2^20 / delta) +- 1
+    int r = (1 << 20) - m * delta;
+    if (r < 0) { m--; r += delta; }
+    if (r >= delta) m++;
+    const uint32_t M = (uint32_t)m + 1u;
+    *A = 15u * M;
+    *B = (uint32_t)((delta >> 1) - 1 + delta - 15 * minCol) * M;
+}

@@ -194,11 +194,13 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             for (int r = 0; r < 4; r++) row[r] = s_px[(cy * 4 + r) * 16 + q * 4 + cx];
         }
         // ---- histogram of the tile's valid pixels, right-most mode (FindAndRemoveMostUsedColor, :8335-8356) --------
+        // bin v is byte v of the tile's 64 words: the add goes to its word, the count comes back with one byte read
+        uint8_t* const histB = reinterpret_cast<uint8_t*>(hist);
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t v = (row[k >> 2] >> (8 * (k & 3))) & 255u;
-                atomicAdd(&hist[v >> 2], 1u << (8 * (v & 3)));
+                atomicAdd(reinterpret_cast<uint32_t*>(histB + (v & 0xFCu)), 1u << ((v << 3) & 31u));
             }
         }
         __syncthreads();
@@ -207,8 +209,7 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t v = (row[k >> 2] >> (8 * (k & 3))) & 255u;
-                const uint32_t cnt = (hist[v >> 2] >> (8 * (v & 3))) & 255u;
-                key = max(key, (int)((cnt << 8) | v));
+                key = max(key, (int)(((uint32_t)histB[v] << 8) | v));
             }
         }
         key = max(key, __shfl_xor(key, 1)); key = max(key, __shfl_xor(key, 4));
@@ -216,12 +217,13 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
         if (color0 == 0) color0 = 1;
         if (color0 == 255) color0 = 254;
         // ---- Model1 over what is left (:8358-8381) ------------------------------------------------------------------
+        const uint32_t c0lo = (uint32_t)(color0 - 1);                         // color0 +- 1  <=>  v - c0lo <= 2 (unsigned)
         int mn = 99999, mx = -99999;
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int v = (int)((row[k >> 2] >> (8 * (k & 3))) & 255u);
-                const bool isC0 = (v >= color0 - 1) && (v <= color0 + 1);
+                const bool isC0 = (uint32_t)v - c0lo <= 2u;
                 mn = isC0 ? mn : min(mn, v); mx = isC0 ? mx : max(mx, v);
             }
         }
@@ -233,23 +235,17 @@ __global__ __launch_bounds__(64) void yk_range1d_kernel(const int32_t* __restric
             uint8_t* slot;
             if (DIRECT) { const uint32_t e = D.offInBlk[ti]; slot = D.pixOut + (size_t)p * D.totals[1] + D.blockP[ti >> 10] + (e >> 11); }
             else slot = slots + ((size_t)p * T8 + ti) * 64;
-            const int round = (delta >> 1) - 1;
+            // GetValueModel1 (:8383-8391) as one multiply-add and a shift per pixel (yk_r1_magic: exact, yk_selftest 4); no branch per pixel
+            uint32_t A, B;
+            yk_r1_magic(delta, minCol, &A, &B);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 uint32_t o4 = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int v = (int)((row[r] >> (8 * i)) & 255u);
-                    int out = 0;
-                    if (!((v >= color0 - 1) && (v <= color0 + 1))) {
-                        int idx = 0;
-                        if (delta) {                                           // GetValueModel1 (:8383-8391), C division truncates toward zero
-                            const int n = (v - minCol) * 15 + round;
-                            idx = n < 0 ? -1 : yk_r1_div(n, delta);           // n < 0 only for delta == 1 (n = -1)
-                        }
-                        out = 1 + idx;
-                    }
-                    o4 |= ((uint32_t)out & 255u) << (8 * i);
+                    const uint32_t v = (row[r] >> (8 * i)) & 255u;
+                    const uint32_t out = (v - c0lo <= 2u) ? 0u : (__umul24(v, A) + B) >> 20;
+                    o4 |= out << (8 * i);
                 }
                 *reinterpret_cast<uint32_t*>(slot + posBase + r * posStep) = o4;
             }

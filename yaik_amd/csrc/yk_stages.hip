@@ -416,6 +416,21 @@ __global__ void yk_selftest_r1div_kernel(int* mismatches) {
     }
 }
 
+// yk_r1_magic against the C expression of GetValueModel1 for every delta, minCol and pixel value the 1-D path can meet
+__global__ void yk_selftest_r1magic_kernel(int* mismatches) {
+    const int delta = blockIdx.x, x = threadIdx.x;               // delta 0..255, x = v - minCol 0..delta
+    if (x > delta) return;
+    for (int minCol = 0; minCol + delta <= 255; minCol++) {
+        uint32_t A, B;
+        yk_r1_magic(delta, minCol, &A, &B);
+        const int v = minCol + x;
+        int idx = 0;
+        if (delta) { const int n = (v - minCol) * 15 + (delta >> 1) - 1; idx = n < 0 ? -1 : n / delta; }
+        const uint32_t got = (__umul24((uint32_t)v, A) + B) >> 20;
+        if (got != (uint32_t)(1 + idx)) atomicAdd(mismatches, 1);
+    }
+}
+
 #ifdef YK_TEST_HOOKS
 extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     if (!c || !result) return YK_ERR_BAD_ARG;
@@ -427,6 +442,7 @@ extern "C" int yk_selftest(yk_ctx* c, int which, int* result) {
     else if (which == 1) hipLaunchKernelGGL(yk_selftest_scale_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else if (which == 2) hipLaunchKernelGGL(yk_selftest_r1div_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else if (which == 3) yk_selftest_qtab_launch(c, d);
+    else if (which == 4) hipLaunchKernelGGL(yk_selftest_r1magic_kernel, dim3(256), dim3(256), 0, c->stream, d);
     else { (void)hipFree(d); return yk_fail(c, YK_ERR_BAD_ARG, "unknown selftest"); }
     YK_HIP(c, hipMemcpyAsync(result, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     YK_HIP(c, hipStreamSynchronize(c->stream));
