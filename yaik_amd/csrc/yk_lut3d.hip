@@ -139,6 +139,19 @@ __device__ __forceinline__ y_us2 yk_us2_from(int b) { y_us2 r = { (unsigned shor
 // |a - b| through the SAD unit (with a literal 0 addend the compiler expands __usad into min / max / sub)
 __device__ __forceinline__ uint32_t yk_absdiff(uint32_t a, uint32_t b) { uint32_t r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// minimum of the wave's 64 values as a wave-uniform number: four DPP steps inside the rows of 16 lanes, the four row minima through readlane.
+// Every lane of the wave must be active.
+template <int CTRL> __device__ __forceinline__ uint32_t yk_dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t yk_wave_min_u32(uint32_t x) {
+    x = min(x, yk_dpp_u32<0xB1>(x));                                        // quad_perm [1,0,3,2]
+    x = min(x, yk_dpp_u32<0x4E>(x));                                        // quad_perm [2,3,0,1]
+    x = min(x, yk_dpp_u32<0x141>(x));                                       // row_half_mirror
+    x = min(x, yk_dpp_u32<0x140>(x));                                       // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 struct LutGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow, mapId; };
 static LutGeo yk_lut_geo(int sx, int sy, int w) {
     LutGeo g; g.sx = sx; g.sy = sy;
@@ -201,6 +214,8 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     __shared__ __attribute__((aligned(16))) int s_cell[128];               // normalised 6-bit coordinates x | y << 8 | z << 16 of the live pixels, compacted
     __shared__ int s_box[6], s_n, s_csq, s_boxw[2][8];                     // s_boxw: per wave, packed minima of the box + live pixels
     __shared__ int s_best[4];                                               // pattern, orientation, bit mode, found
+    __shared__ int s_nrc[3];                                                // (1 << 20) / d per channel
+    __shared__ float s_rcf[3];                                              // RN(1 / d) per channel
     // sized by the bank at launch (a 64-pattern bank needs 17 KB, the usual handful 2 KB)
     extern __shared__ int s_dyn[];
     const int nPat = bank.nPat;
@@ -250,11 +265,16 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         }
     }
     __syncthreads();
-    if (t < 7) {                                                            // fold the two waves' halves; empty = {9999 x3, -1 x3} as the reference leaves it
-        const int m0 = s_boxw[0][t], m1 = NT > 64 ? s_boxw[1][t] : (t == 6 ? 0 : 0xFFFF);
-        if (t == 6) s_n = m0 + m1;
-        else { const int m = min(m0, m1); s_box[t] = t < 3 ? (m == 0xFFFF ? 9999 : m) : (m == 0xFFFF ? -1 : 255 - m); }
+    if (t < 3) {                                                            // fold the two waves' halves; empty = {9999 x3, -1 x3} as the reference leaves it
+        const int ml = min(s_boxw[0][t], NT > 64 ? s_boxw[1][t] : 0xFFFF), mh = min(s_boxw[0][3 + t], NT > 64 ? s_boxw[1][3 + t] : 0xFFFF);
+        const int bl = ml == 0xFFFF ? 9999 : ml, bh = mh == 0xFFFF ? -1 : 255 - mh, bd = bh - bl;
+        s_box[t] = bl; s_box[3 + t] = bh;
+        // the channel's two reciprocals, computed once per tile in these three lanes instead of per pixel (an integer division is ~35 instructions of
+        // the wave whoever needs the result): (1 << 20) / d for the scoring coordinates, RN(1 / d) for the exact float division of the entry evaluation
+        s_nrc[t] = bd > 0 ? (1 << 20) / bd : 0;
+        s_rcf[t] = bd > 0 ? __fdiv_rn(1.0f, (float)bd) : 0.0f;
     }
+    if (t == 6) s_n = s_boxw[0][6] + (NT > 64 ? s_boxw[1][6] : 0);
     __syncthreads();
     const int pixels = s_n;
     int lo[3], d[3];
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         if (live) {
             int q[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) { const int n = d[c] ? (1 << 20) / d[c] : 0; const float f = __fdiv_rn((float)((v[c] - lo[c]) * n), 1048576.0f); q[c] = (int)__fmul_rn(f, 63.0f); }
+            for (int c = 0; c < 3; c++) { const int n = s_nrc[c]; const float f = __fmul_rn((float)((v[c] - lo[c]) * n), 1.0f / 1048576.0f); q[c] = (int)__fmul_rn(f, 63.0f); }   // / 2^20 is exact either way
             s_cell[rank] = q[0] | (q[1] << 8) | (q[2] << 16);
             csq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
         }
@@ -327,20 +347,18 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     if (t == 0) slots[pos].found = s_sum[0] == 12345;
     return;
 #endif
-    // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float.  A wave per pattern: the quotients are not negative, so
-    // their bit patterns order like the values; the winner is the first lane that holds the wave's minimum.
+    // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float.  The sums are integers below 2^21 (128 pixels x 3 x 63^2) and the
+    // divisor is the same for all of them, so two different sums differ by more than 2^-21 relatively and their float quotients differ too: the first
+    // minimum of the quotients is the first minimum of the integers.  A wave per pattern: key = sum << 6 | lane, one wave minimum gives both.
     {
-        const float den = __fmul_rn((float)pixels, 1024.0f);
-        const int l = t & 63;
-        for (int k = t >> 6; k < nPat; k += NT >> 6) {
+        const int l = t & 63, wv0 = __builtin_amdgcn_readfirstlane(t >> 6);
+        for (int k = wv0; k < nPat; k += NT >> 6) {
             const int first0 = bank.patStart[k], cnt = bank.patStart[k + 1] - first0;
-            uint32_t key = 0xFFFFFFFFu;
-            if (l < cnt) key = __float_as_uint(__fdiv_rn((float)s_sum[first0 + l], den));
-            uint32_t mn = key;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-            const unsigned long long first = __ballot(key == mn);
-            if (l == 0) s_mode[k] = bank.pairMode[first0 + __ffsll((long long)first) - 1];
+            const uint32_t pm = l < cnt ? bank.pairMode[first0 + l] : 0u;     // in flight under the reduction, picked by lane number after it
+            const uint32_t key = l < cnt ? (((uint32_t)s_sum[first0 + l] << 6) | (uint32_t)l) : 0xFFFFFFFFu;
+            const uint32_t mn = yk_wave_min_u32(key);
+            const int mode = __builtin_amdgcn_readlane((int)pm, (int)(mn & 63u));
+            if (l == 0) s_mode[k] = mode;
         }
     }
     __syncthreads();
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float rel = liveP ? (float)(v[c] - lo[c]) : 0.0f;
-        if (d[c]) rel = __fdiv_rn(rel, (float)d[c]);
+        rel = yk_div_exact(rel, (float)d[c], s_rcf[c]);                    // == __fdiv_rn for 0..255 / 1..255 (yk_selftest 0); d == 0: rel is 0 and stays 0
         relp[c] = __fmul_rn(rel, 63.0f);
     }
     // the cell of this pixel in pattern space under orientation `mode`
@@ -417,11 +435,12 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     if (t == 0) slots[pos].found = s_part[0][4] == 12345;
     return;
 #endif
-    if (t == 0) {
+    if (t < 64) {
         // :6066-6069 (lowest depth that is not rejected, a depth is rejected when more than 3 pixels are off by more than 5) and the choice
-        // among patterns :6486 (smallest summed error, the LATER pattern on a tie)
-        int found = 0, bestK = -1, bestMode = 4, diffSum = (int)99999999999LL;
-        for (int k = 0; k < nPat; k++) {
+        // among patterns :6486 (smallest summed error, the LATER pattern on a tie): lane = pattern, key = error << 14 | (4095 - pattern) << 2 | depth,
+        // one wave minimum instead of a loop over the patterns in one lane
+        uint32_t bestKey = 0xFFFFFFFFu;
+        for (int k = t; k < nPat; k += 64) {
             int acc[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) acc[i] = s_part[k][i] + (NT > 64 ? s_part[nPat + k][i] : 0);
@@ -430,15 +449,20 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
             if (acc[5] <= 3) { diff = acc[1]; res = 2; }
             if (acc[6] <= 3) { diff = acc[2]; res = 1; }
             if (acc[7] <= 3) { diff = acc[3]; res = 0; }
-            if (res != 4 && diff <= diffSum) { found = 1; bestK = k; bestMode = res; diffSum = diff; }
+            if (res != 4) bestKey = min(bestKey, ((uint32_t)diff << 14) | ((uint32_t)(4095 - k) << 2) | (uint32_t)res);
         }
-        s_best[0] = bestK; s_best[1] = found ? s_mode[bestK] : 0; s_best[2] = bestMode; s_best[3] = found;
-        LutSlot sl;
-        sl.found = (uint8_t)found; sl.pixels = (uint8_t)pixels; sl.mode = (uint8_t)bestMode; sl.pad = 0;
-        sl.type = (uint16_t)((found ? s_mode[bestK] : 0) | (bestMode << 14) | ((found ? bestK : 0) << 6));        // :6559
-        for (int c = 0; c < 6; c++) sl.box[c] = (uint8_t)s_box[c];
-        slots[pos] = sl;
-        if (found) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        const uint32_t mk = yk_wave_min_u32(bestKey);
+        if (t == 0) {
+            const int found = mk != 0xFFFFFFFFu, bestK = found ? 4095 - (int)((mk >> 2) & 4095u) : -1, bestMode = found ? (int)(mk & 3u) : 4;
+            const int bestOrient = found ? s_mode[bestK] : 0;
+            s_best[0] = bestK; s_best[1] = bestOrient; s_best[2] = bestMode; s_best[3] = found;
+            LutSlot sl;
+            sl.found = (uint8_t)found; sl.pixels = (uint8_t)pixels; sl.mode = (uint8_t)bestMode; sl.pad = 0;
+            sl.type = (uint16_t)(bestOrient | (bestMode << 14) | ((found ? bestK : 0) << 6));        // :6559
+            for (int c = 0; c < 6; c++) sl.box[c] = (uint8_t)s_box[c];
+            slots[pos] = sl;
+            if (found) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        }
     }
     __syncthreads();
     if (!s_best[3]) return;
