@@ -207,7 +207,29 @@ __global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __res
 // ---- one workgroup per tile: 128 threads for the 128-pixel shapes, one wave for the others -------------------------------------------
 // Thread t holds pixel t & (nPix - 1) in the order computeValues3D walks the tile (left 8 columns first for 16-wide tiles, :5856-5859); with
 // fewer than 64 pixels the wave holds the tile 64 / nPix times and every copy evaluates its own share of the patterns.
-__global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
+// Byte selectors (v_perm_b32) of the 48 orientations, orientation = flips | swap << 3:  c[] takes a pixel's cell from its plain (bytes 0-2 of the
+// second operand) and flipped (bytes 0-2 of the first) 6-bit coordinates -- flip by channel, then swap3D; b[] applies the inverse swap to three bytes.
+// Selected per lane with nested ?: the swaps compiled to exec-mask branches (half of the entry evaluation's instructions); a selector is one LDS read.
+struct YkLutSelTab { uint32_t c[48], b[48]; };
+constexpr YkLutSelTab yk_lut_make_sel_tab() {
+    constexpr int SRC[6][3] = { { 0, 1, 2 }, { 0, 2, 1 }, { 1, 0, 2 }, { 1, 2, 0 }, { 2, 0, 1 }, { 2, 1, 0 } };      // swap3D (:5314-5354): new (x, y, z) = old [SRC]
+    YkLutSelTab T{};
+    for (int m = 0; m < 48; m++) {
+        const int sw = m >> 3, back = sw == 3 ? 4 : (sw == 4 ? 3 : sw);                                               // the inverse of swap 3 is swap 4; the others are involutions
+        uint32_t c = 0x0C000000u, b = 0x0C000000u;
+        for (int j = 0; j < 3; j++) {
+            const int src = SRC[sw][j];
+            c |= (uint32_t)(src + (((m >> src) & 1) ? 4 : 0)) << (8 * j);
+            b |= (uint32_t)SRC[back][j] << (8 * j);
+        }
+        T.c[m] = c; T.b[m] = b;
+    }
+    return T;
+}
+__constant__ YkLutSelTab yk_lut_sel_tab = yk_lut_make_sel_tab();
+
+template <int SX, int SY>
+__global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
                                                             int w, int h, LutGeo g, const YkLutBank bank, uint32_t* __restrict__ covCh32, size_t covStride,
                                                             int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap,
                                                             const uint32_t* __restrict__ list) {
@@ -222,7 +244,10 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     int* const s_sum = s_dyn;                                               // [nPairs <= nPat * 48]: the scores
     int* const s_mode = s_sum + nPat * 48;                                  // [nPat]: first orientation with the smallest score
     int (*const s_part)[8] = reinterpret_cast<int (*)[8]>(s_mode + nPat);   // [2 waves][nPat][8]: absErr of 6,5,4,3 bit; pixels with error > 5 of 6,5,4,3 bit
-    const int t = threadIdx.x, NT = blockDim.x, TX = 1 << g.sx, TY = 1 << g.sy, nPix = TX * TY;      // NT = 128, or 64 for tiles of at most 64 pixels
+    __shared__ uint2 s_sel[48];                                             // cell and back-swap selectors of every orientation
+    constexpr int TX = 1 << SX, TY = 1 << SY, nPix = TX * TY, NT = nPix > 64 ? 128 : 64;             // the shape is a template parameter: shuffle widths, copies and loops are constants
+    const int t = threadIdx.x;
+    if (t < 48) s_sel[t] = make_uint2(yk_lut_sel_tab.c[t], yk_lut_sel_tab.b[t]);
     const uint32_t pos = list[1 + blockIdx.x];                               // the candidate tiles of the pass (yk_lut_list_kernel)
     const uint32_t blk = pos / (uint32_t)g.bitCount, tt = pos % (uint32_t)g.bitCount;
     const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
@@ -231,7 +256,8 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
     if (t == 0) s_csq = 0;
     // buildBBox3D (:132-193): a pixel is out when all three planes already cover it; the box spans the others
     const int tp = t & (nPix - 1);                                          // the thread's pixel; the first nPix threads are the tile, the others copies
-    const int copy = t / nPix, nCopies = NT / nPix;
+    constexpr int nCopies = NT / nPix;
+    const int copy = t / nPix;
     int v[3] = { 0, 0, 0 };
     bool liveP;
     {
@@ -372,32 +398,39 @@ __global__ __launch_bounds__(128) void yk_lut_search_kernel(const int32_t* __res
         rel = yk_div_exact(rel, (float)d[c], s_rcf[c]);                    // == __fdiv_rn for 0..255 / 1..255 (yk_selftest 0); d == 0: rel is 0 and stays 0
         relp[c] = __fmul_rn(rel, 63.0f);
     }
+    // plain and flipped 6-bit coordinates, W = v - lo and d as packed bytes: an orientation's flip + swap is one v_perm_b32 with its selector
+    const uint32_t MI = (uint32_t)(int)relp[0] | ((uint32_t)(int)relp[1] << 8) | ((uint32_t)(int)relp[2] << 16);
+    const uint32_t MF = (uint32_t)(int)__fsub_rn(63.0f, relp[0]) | ((uint32_t)(int)__fsub_rn(63.0f, relp[1]) << 8) | ((uint32_t)(int)__fsub_rn(63.0f, relp[2]) << 16);
+    const uint32_t Wp = liveP ? ((uint32_t)(v[0] - lo[0]) | ((uint32_t)(v[1] - lo[1]) << 8) | ((uint32_t)(v[2] - lo[2]) << 16)) : 0u;
+    const uint32_t Dp = (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16);                // 0..255 each once a tile is accepted
     // the cell of this pixel in pattern space under orientation `mode`
     auto cellOf = [&](int mode) {
-        int m[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) m[c] = ((mode >> c) & 1) ? (int)__fsub_rn(63.0f, relp[c]) : (int)relp[c];
-        yk_lut_swap(mode >> 3, m[0], m[1], m[2]);
-        return m[0] + m[1] * 64 + (m[2] << 12);
+        const uint32_t cm = __builtin_amdgcn_perm(MF, MI, s_sel[mode].x);
+        return (int)((cm & 63u) | ((cm >> 2) & 0xFC0u) | ((cm >> 4) & 0x3F000u));
     };
     // per pattern: the four depths' worst-channel errors of this pixel, summed over the tile's lanes with shuffles that stay inside the copy
     // (two 16-bit sums per word: a tile holds at most 128 pixels of error <= 255) and ballots for the ">5" counts; LDS atomics on eight
     // shared words per pattern serialised all 64 lanes of a wave and were the larger half of the first version's time
     {
-        const int wv = t >> 6, seg = min(nPix, 64);
+        const int wv = t >> 6;
+        constexpr int seg = nPix < 64 ? nPix : 64;
         const unsigned long long segMask = seg == 64 ? ~0ULL : (((1ULL << seg) - 1ULL) << ((t & 63) - tp));
         // The colour of an entry (:5889-5925) is lo + ((swap(flip(factors)) * d) / FACTOR) per channel and its error max |colour - v|.  Seen from the
         // pattern's axes: axis a drives the channel the swap sends it to, so with W = v - lo and d permuted the other way ONCE per pattern, an axis
         // costs mad (flip folded in: (F ? 128 - f : f) * d = f * (+-d) + (F ? 128 d : 0)), shift (all operands are >= 0), |x - W| per depth.
         auto evalPattern = [&](const int k, int (&w4)[4]) {
-            const int mode = s_mode[k], sw = mode >> 3, back = sw == 3 ? 4 : (sw == 4 ? 3 : sw);     // the inverse of swap 3 is swap 4; the others are involutions
-            const uint32_t entries = bank.pos[(size_t)k * LUT_CUBE + cellOf(mode)];
-            int W[3] = { v[0] - lo[0], v[1] - lo[1], v[2] - lo[2] }, D[3] = { d[0], d[1], d[2] };
-            yk_lut_swap(back, W[0], W[1], W[2]);
-            yk_lut_swap(back, D[0], D[1], D[2]);
-            int SD[3], BD[3];
+            const int mode = s_mode[k];
+            const uint2 sel = s_sel[mode];
+            const uint32_t cm = __builtin_amdgcn_perm(MF, MI, sel.x);
+            const uint32_t entries = bank.pos[(size_t)k * LUT_CUBE + ((cm & 63u) | ((cm >> 2) & 0xFC0u) | ((cm >> 4) & 0x3F000u))];
+            const uint32_t Wq = __builtin_amdgcn_perm(0u, Wp, sel.y), Dq = __builtin_amdgcn_perm(0u, Dp, sel.y);
+            int W[3], SD[3], BD[3];
 #pragma unroll
-            for (int a = 0; a < 3; a++) { const bool F = (mode >> a) & 1; SD[a] = F ? -D[a] : D[a]; BD[a] = F ? LUT_FACTOR * D[a] : 0; }
+            for (int a = 0; a < 3; a++) {
+                const int Da = (int)((Dq >> (8 * a)) & 255u);
+                const bool F = (mode >> a) & 1;
+                W[a] = (int)((Wq >> (8 * a)) & 255u); SD[a] = F ? -Da : Da; BD[a] = F ? LUT_FACTOR * Da : 0;
+            }
 #pragma unroll
             for (int depth = 0; depth < 4; depth++) {
                 const short4 f = bank.fac[(k * 4 + depth) * 64 + (int)((entries >> (8 * depth)) & 255u)];
@@ -692,8 +725,18 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     YK_HIP(c, hipStreamSynchronize(c->stream));                              // the grid of the search is the number of candidates
     if (nCand) {
         { int rc = yk_stage_begin(c, YK_STAGE_LUT3D); if (rc) return rc; }
-        hipLaunchKernelGGL(yk_lut_search_kernel, dim3(nCand), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream, c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g,
-                           bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx, reinterpret_cast<uint32_t*>(S->map[g.mapId]), S->list);
+#define YK_LUT_LAUNCH(SX_, SY_) hipLaunchKernelGGL((yk_lut_search_kernel<SX_, SY_>), dim3(nCand), dim3(nPix > 64 ? 128 : 64), (size_t)S->nPat * (48 + 1 + 16) * sizeof(int), c->stream,       \
+                           c->plane[0], c->plane[1], c->plane[2], c->strideElems, w, h, g, bank, reinterpret_cast<uint32_t*>(c->covCh), c->covChStride, c->mtW, slots, slotIdx,               \
+                           reinterpret_cast<uint32_t*>(S->map[g.mapId]), S->list)
+        switch (g.mapId) {                                                  // one instantiation per tile shape
+            case 0: YK_LUT_LAUNCH(4, 3); break;
+            case 1: YK_LUT_LAUNCH(3, 4); break;
+            case 2: YK_LUT_LAUNCH(3, 3); break;
+            case 3: YK_LUT_LAUNCH(3, 2); break;
+            case 4: YK_LUT_LAUNCH(2, 3); break;
+            default: YK_LUT_LAUNCH(2, 2); break;
+        }
+#undef YK_LUT_LAUNCH
         { int rc = yk_stage_end(c, YK_STAGE_LUT3D); if (rc) return rc; }
     }
     hipLaunchKernelGGL(yk_lut_count_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, slots, nSlots, sums, nb);
