@@ -152,6 +152,31 @@ __device__ __forceinline__ uint32_t yk_wave_min_u32(uint32_t x) {
     return min(min(r0, r1), min(r2, r3));
 }
 
+// sums / packed 16-bit minima over rows of 16 lanes (every lane of the row ends with the row's value), then over a segment of ROWS consecutive
+// rows: lanes that start a segment read the other rows' values through readlane-free xor shuffles (one or two ds_bpermute instead of six)
+__device__ __forceinline__ int yk_row_sum(int x) {
+    x += (int)yk_dpp_u32<0xB1>((uint32_t)x); x += (int)yk_dpp_u32<0x4E>((uint32_t)x); x += (int)yk_dpp_u32<0x141>((uint32_t)x); x += (int)yk_dpp_u32<0x140>((uint32_t)x);
+    return x;
+}
+template <int SEG> __device__ __forceinline__ int yk_seg_sum(int x) {       // SEG = 16, 32 or 64 lanes
+    x = yk_row_sum(x);
+    if (SEG >= 32) x += __shfl_xor(x, 16);
+    if (SEG >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+typedef unsigned short yk_us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t yk_pkmin_u16(uint32_t a, uint32_t b) {
+    yk_us2v x = { (unsigned short)(a & 0xFFFFu), (unsigned short)(a >> 16) }, y = { (unsigned short)(b & 0xFFFFu), (unsigned short)(b >> 16) };
+    const yk_us2v m = __builtin_elementwise_min(x, y);
+    return (uint32_t)m.x | ((uint32_t)m.y << 16);
+}
+template <int SEG> __device__ __forceinline__ uint32_t yk_seg_pkmin_u16(uint32_t x) {
+    x = yk_pkmin_u16(x, yk_dpp_u32<0xB1>(x)); x = yk_pkmin_u16(x, yk_dpp_u32<0x4E>(x)); x = yk_pkmin_u16(x, yk_dpp_u32<0x141>(x)); x = yk_pkmin_u16(x, yk_dpp_u32<0x140>(x));
+    if (SEG >= 32) x = yk_pkmin_u16(x, (uint32_t)__shfl_xor((int)x, 16));
+    if (SEG >= 64) x = yk_pkmin_u16(x, (uint32_t)__shfl_xor((int)x, 32));
+    return x;
+}
+
 struct LutGeo { int sx, sy, bigX, bigY, bitCount, xBB, tilesPerRow, mapId; };
 static LutGeo yk_lut_geo(int sx, int sy, int w) {
     LutGeo g; g.sx = sx; g.sy = sy;
@@ -249,9 +274,10 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     const int t = threadIdx.x;
     if (t < 48) s_sel[t] = make_uint2(yk_lut_sel_tab.c[t], yk_lut_sel_tab.b[t]);
     const uint32_t pos = list[1 + blockIdx.x];                               // the candidate tiles of the pass (yk_lut_list_kernel)
-    const uint32_t blk = pos / (uint32_t)g.bitCount, tt = pos % (uint32_t)g.bitCount;
-    const int x0 = (int)(blk % (uint32_t)g.xBB) * g.bigX + (int)(tt % (uint32_t)g.tilesPerRow) * TX;
-    const int y0 = (int)(blk / (uint32_t)g.xBB) * g.bigY + (int)(tt / (uint32_t)g.tilesPerRow) * TY;
+    constexpr int bigX = SX == 2 ? 32 : 64, bigY = SY == 2 ? 32 : 64, tilesPerRow = bigX >> SX, bitCount = tilesPerRow * (bigY >> SY);      // yk_lut_geo: powers of two
+    const uint32_t blk = pos / (uint32_t)bitCount, tt = pos % (uint32_t)bitCount;
+    const int x0 = (int)(blk % (uint32_t)g.xBB) * bigX + (int)(tt % (uint32_t)tilesPerRow) * TX;
+    const int y0 = (int)(blk / (uint32_t)g.xBB) * bigY + (int)(tt / (uint32_t)tilesPerRow) * TY;
     if (x0 + TX > w || y0 + TY > h) { if (t == 0) slots[pos].found = 0; return; }             // partial tiles are never tried (:6304, :6311)
     if (t == 0) s_csq = 0;
     // buildBBox3D (:132-193): a pixel is out when all three planes already cover it; the box spans the others
@@ -276,18 +302,14 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     const unsigned long long bal = __ballot(live);
     {   // the box through wave reductions on packed 16-bit minima (max = 255 - min of 255 - v): the first version's LDS atomics on seven shared
         // words were serialised lane by lane, 2.3 of a pass's 8 ms at 8192^2
-        y_us2 a = { (unsigned short)(live ? v[0] : 0xFFFF), (unsigned short)(live ? v[1] : 0xFFFF) };
-        y_us2 b = { (unsigned short)(live ? v[2] : 0xFFFF), (unsigned short)(live ? 255 - v[0] : 0xFFFF) };
-        y_us2 c = { (unsigned short)(live ? 255 - v[1] : 0xFFFF), (unsigned short)(live ? 255 - v[2] : 0xFFFF) };
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            a = __builtin_elementwise_min(a, yk_us2_from(__shfl_xor((int)yk_us2_bits(a), off)));
-            b = __builtin_elementwise_min(b, yk_us2_from(__shfl_xor((int)yk_us2_bits(b), off)));
-            c = __builtin_elementwise_min(c, yk_us2_from(__shfl_xor((int)yk_us2_bits(c), off)));
-        }
+        // DPP steps inside the rows of 16 lanes; only the rows that hold pixels are combined (the copies of a small tile contribute 0xFFFF)
+        constexpr int boxSeg = nPix < 64 ? nPix : 64;
+        const uint32_t a = yk_seg_pkmin_u16<boxSeg>(live ? ((uint32_t)v[0] | ((uint32_t)v[1] << 16)) : 0xFFFFFFFFu);
+        const uint32_t b = yk_seg_pkmin_u16<boxSeg>(live ? ((uint32_t)v[2] | ((uint32_t)(255 - v[0]) << 16)) : 0xFFFFFFFFu);
+        const uint32_t c = yk_seg_pkmin_u16<boxSeg>(live ? ((uint32_t)(255 - v[1]) | ((uint32_t)(255 - v[2]) << 16)) : 0xFFFFFFFFu);
         if ((t & 63) == 0) {
             int* o = s_boxw[t >> 6];
-            o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = __popcll(bal);
+            o[0] = (int)(a & 0xFFFFu); o[1] = (int)(a >> 16); o[2] = (int)(b & 0xFFFFu); o[3] = (int)(b >> 16); o[4] = (int)(c & 0xFFFFu); o[5] = (int)(c >> 16); o[6] = __popcll(bal);
         }
     }
     __syncthreads();
@@ -323,8 +345,7 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
             s_cell[rank] = q[0] | (q[1] << 8) | (q[2] << 16);
             csq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) csq += __shfl_xor(csq, off);
+        csq = yk_seg_sum<(nPix < 64 ? nPix : 64)>(csq);                      // lanes past the tile's pixels hold 0
         if ((t & 63) == 0 && csq) atomicAdd(&s_csq, csq);
     }
     __syncthreads();
@@ -442,7 +463,7 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
         };
         auto reducePattern = [&](const int k, const int (&w4)[4]) {
             int s01 = w4[0] | (w4[1] << 16), s23 = w4[2] | (w4[3] << 16);
-            for (int off = seg >> 1; off >= 1; off >>= 1) { s01 += __shfl_xor(s01, off); s23 += __shfl_xor(s23, off); }
+            s01 = yk_seg_sum<seg>(s01); s23 = yk_seg_sum<seg>(s23);
             const int c0 = __popcll(__ballot(w4[0] > 5) & segMask), c1 = __popcll(__ballot(w4[1] > 5) & segMask);
             const int c2 = __popcll(__ballot(w4[2] > 5) & segMask), c3 = __popcll(__ballot(w4[3] > 5) & segMask);
             if ((tp & 63) == 0 && k < nPat) {
