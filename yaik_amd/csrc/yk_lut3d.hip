@@ -18,6 +18,7 @@
 #include "yk_common.h"
 #include "yk_device.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -33,12 +34,13 @@ struct YkLutPattern { uint16_t* dist; uint32_t* pos; short4* fac; int count; }; 
 // pos[pattern * 64^3 + cell] = the cell's nearest entry at 6 | 5 << 8 | 4 << 16 | 3 << 24 bits (one gather serves the four depths: the gathers into
 // these 1 MB tables are what the search waits for); fac[(pattern * 4 + depth) * 64 + entry] = the entry's three factors (x, y, z, 0).  One allocation
 // per table for the whole bank, passed as kernel arguments: no pointer per pattern to fetch first.
-struct YkLutBank { const uint2* ptab; const uint8_t* pairMode; const int* patStart; const uint32_t* pos; const short4* fac; int nPat, nPairs; };
+struct YkLutBank { const uint2* ptab; const uint2* ptabM; const uint8_t* pairMode; const int* patStart; const uint32_t* pos; const short4* fac; int nPat, nPairs; };
 struct YkLutState {
     YkLutPattern pat[LUT_MAXPAT]; int nPat = 0;
     uint2* ptab = nullptr;                  // [<= LUT_MAXPAT * 48 pairs][8], 192 KB
+    uint2* ptabM = nullptr;                 // the same points as rows of the MFMA scoring's A operand (see yk_lut_search_kernel), 64 zero rows behind them
     uint8_t* pairMode = nullptr; int* patStart = nullptr;
-    std::vector<uint2> hPtab; std::vector<uint8_t> hPairMode; std::vector<int> hPatStart = { 0 };      // host copies, grown by every yk_lut_load_pattern
+    std::vector<uint2> hPtab, hPtabM; std::vector<uint8_t> hPairMode; std::vector<int> hPatStart = { 0 };      // host copies, grown by every yk_lut_load_pattern
     uint32_t* posAll = nullptr;             // [LUT_MAXPAT][64^3], 64 MB (allocated with the first pattern)
     short4* facAll = nullptr;               // [LUT_MAXPAT][4][64]
     bool started = false;
@@ -272,7 +274,6 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     __shared__ uint2 s_sel[48];                                             // cell and back-swap selectors of every orientation
     constexpr int TX = 1 << SX, TY = 1 << SY, nPix = TX * TY, NT = nPix > 64 ? 128 : 64;             // the shape is a template parameter: shuffle widths, copies and loops are constants
     const int t = threadIdx.x;
-    if (t < 48) s_sel[t] = make_uint2(yk_lut_sel_tab.c[t], yk_lut_sel_tab.b[t]);
     const uint32_t pos = list[1 + blockIdx.x];                               // the candidate tiles of the pass (yk_lut_list_kernel)
     constexpr int bigX = SX == 2 ? 32 : 64, bigY = SY == 2 ? 32 : 64, tilesPerRow = bigX >> SX, bitCount = tilesPerRow * (bigY >> SY);      // yk_lut_geo: powers of two
     const uint32_t blk = pos / (uint32_t)bitCount, tt = pos % (uint32_t)bitCount;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     if (t == 0) slots[pos].found = 0;
     return;
 #endif
+    if (t < 48) s_sel[t] = make_uint2(yk_lut_sel_tab.c[t], yk_lut_sel_tab.b[t]);                 // accepted tiles only; read after the next barriers
     const int rank = __popcll(bal & ((1ULL << (t & 63)) - 1ULL)) + (t >= 64 ? s_boxw[0][6] : 0);  // position among the live pixels (thread order = the reference's walk)
     {   // coordinates for the scoring (:6389-6405): (int)(((v - lo) * ((1 << 20) / d)) / 2^20 * 63) in float
         int csq = 0;
@@ -353,7 +355,91 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     // with its eight transformed points in registers (the next round's are loaded under this round's arithmetic), the pixels come as LDS
     // broadcasts: 8 dot products + 4 min3 + 1 add per pixel and lane.
     const int nPairs = bank.nPairs;
-    {
+    if constexpr (nPix >= 64) {
+        // Tiles of 64 pixels and more: the (point, pixel) products on the matrix cores (with one chunk of 32 pixels per tile the per-group sums and
+        // table loads cost more than the products save: 8x4 / 4x8 tiles took 1.89 ms instead of 1.62).  v_mfma_i32_32x32x16_i8 with rows = the 32 points of four
+        // pairs, columns = 32 pixels, K = (x, y, z, 127, 1) against (-2 px, -2 py, -2 pz, a, b), |p|^2 = 127 a + b: D[point][pixel] = |p|^2 - 2 c.p.
+        // Rows are ordered so that a lane's sixteen results (rows 8 b + 4 h + r of column lane & 31, h = lane >> 5; layout checked on the part by
+        // tools/ubench/mfma_i8_layout.hip) are ALL eight points of two pairs: pair 2 h + (b >> 1), point 4 (b & 1) + r -- the minimum over a pair's
+        // points stays inside the lane (4 v_min3 / v_min per pair and 32 pixels instead of 12.5 VALU instructions per pixel and 64 pairs), lanes 0-31
+        // accumulate pairs 0 and 1 of the group, lanes 32-63 pairs 2 and 3, and a 32-lane sum per pair closes the group.
+        typedef int yk_v16i __attribute__((ext_vector_type(16)));
+        constexpr int maxChunks = nPix / 32;
+        const int csqAll = s_csq;
+        const int l = t & 63, wv0 = __builtin_amdgcn_readfirstlane(t >> 6);
+        long Bop[maxChunks];
+#pragma unroll
+        for (int ch = 0; ch < maxChunks; ch++) {
+            const int pp = ch * 32 + (l & 31);
+            Bop[ch] = (l < 32 && pp < pixels) ? (long)(((unsigned long long)1u << 32) | (unsigned long long)((uint32_t)s_cell[pp] | 0x7F000000u)) : 0L;   // a missing pixel scores 0 everywhere
+        }
+        const int nCh = (YK_LUT_ABLATE == 1) ? 0 : (pixels + 31) >> 5;
+        const int nGroups = (nPairs + 3) >> 2;
+        // row of this lane in a group of 32 table entries (4 pairs x 8 points): row i = 8 b + 4 h + r  ->  pair 2 h + (b >> 1), point 4 (b & 1) + r
+        const int rowOff = ((((l >> 2) & 1) * 2 + ((l >> 4) & 1)) * 8) + (((l >> 3) & 1) * 4) + (l & 3);
+        // no branch around the load (the compiler then counts the loads in flight exactly): lanes 32-63, whose half of K is not used, and groups past
+        // the last one read the zero rows behind the table
+        auto loadA = [&](const int G) -> long {
+            const uint2 e = bank.ptabM[l < 32 ? min(G, nGroups) * 32 + rowOff : nPairs * 8];
+            return (long)(((unsigned long long)e.y << 32) | (unsigned long long)e.x);
+        };
+        // Four groups (16 pairs) per step and wave.  Their table rows are loaded a step ahead into the other of two register sets (no copy at the end of
+        // a step, so the loads stay in flight under it), and their eight per-lane sums are added over the 32 pixel lanes TOGETHER: three combine steps
+        // (lanes l and l ^ 1, l ^ 2, l ^ 8 split the values between them, each keeping half and adding the partner's share) leave one register, two
+        // plain steps (l ^ 4, l ^ 16) finish it -- 25 instructions for eight sums instead of 8 x 6.  Lane bits afterwards: bit 0 = second pair of the
+        // lane half, bit 1 | bit 3 << 1 = group of the step, bit 5 = lane half; lanes with bits 2 and 4 clear store.
+        constexpr int STEP = (NT >> 6) * 4;
+        auto loadA4 = [&](const int g0, long (&A)[4]) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) A[g] = loadA(g0 + g);
+        };
+        auto combine = [&](const bool low, const int a, const int b, auto ctrl) {
+            const int keep = low ? a : b, send = low ? b : a;
+            return keep + (int)yk_dpp_u32<decltype(ctrl)::value>((uint32_t)send);
+        };
+        auto process = [&](const int g0, const long (&A)[4]) {
+            int vs[8];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                int accA = 0, accB = 0;
+                if (g0 + g < nGroups) {
+#pragma unroll
+                    for (int ch = 0; ch < maxChunks; ch++) {
+                        if (ch < nCh) {
+                            const yk_v16i z = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                            const yk_v16i dd = __builtin_amdgcn_mfma_i32_32x32x16_i8(A[g], Bop[ch], z, 0, 0, 0);
+                            accA += min(min(min(dd[0], dd[1]), min(dd[2], dd[3])), min(min(dd[4], dd[5]), min(dd[6], dd[7])));
+                            accB += min(min(min(dd[8], dd[9]), min(dd[10], dd[11])), min(min(dd[12], dd[13]), min(dd[14], dd[15])));
+                        }
+                    }
+                }
+                vs[2 * g] = accA; vs[2 * g + 1] = accB;
+            }
+            const bool low1 = !(l & 1), low2 = !(l & 2), low3 = !(l & 8);
+            const std::integral_constant<int, 0xB1> X1; const std::integral_constant<int, 0x4E> X2; const std::integral_constant<int, 0x128> X8;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:8
+            const int w0 = combine(low1, vs[0], vs[1], X1), w1 = combine(low1, vs[2], vs[3], X1), w2 = combine(low1, vs[4], vs[5], X1), w3 = combine(low1, vs[6], vs[7], X1);
+            const int x0 = combine(low2, w0, w1, X2), x1 = combine(low2, w2, w3, X2);
+            int y = combine(low3, x0, x1, X8);
+            y += (int)yk_dpp_u32<0x1B>(yk_dpp_u32<0x141>((uint32_t)y));     // lane l ^ 4: row_half_mirror, then the quad reversed
+            y += __shfl_xor(y, 16);
+            if (!(l & 20)) {
+                const int pi = (g0 + ((l >> 2) & 2) + ((l >> 1) & 1)) * 4 + (l >> 5) * 2 + (l & 1);
+                if (pi < nPairs) s_sum[pi] = y + csqAll;
+            }
+        };
+        long A0[4], A1[4];
+        int g0 = wv0 * 4;
+        loadA4(g0, A0);
+        while (g0 < nGroups) {
+            loadA4(g0 + STEP, A1);
+            process(g0, A0);
+            g0 += STEP;
+            if (g0 >= nGroups) break;
+            loadA4(g0 + STEP, A0);
+            process(g0, A1);
+            g0 += STEP;
+        }
+    } else {
         const int csqAll = s_csq;
         auto points = [&](const int pi, uint4 (&q)[4]) {
             const uint4* __restrict__ pt = reinterpret_cast<const uint4*>(bank.ptab + (size_t)min(pi, nPairs - 1) * 8);
@@ -585,7 +671,7 @@ static void yk_lut_release(yk_ctx* c) {
     YkLutState* S = c->lut; if (!S) return;
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int k = 0; k < S->nPat; k++) F(S->pat[k].dist);
-    F(S->ptab); F(S->pairMode); F(S->patStart); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->list); F(S->tileType); F(S->color);
+    F(S->ptab); F(S->ptabM); F(S->pairMode); F(S->patStart); F(S->posAll); F(S->facAll); F(S->slots); F(S->slotIdx); F(S->sums); F(S->list); F(S->tileType); F(S->color);
     for (auto& p : S->idx) F(p);
     for (auto& p : S->map) F(p);
     delete S; c->lut = nullptr;
@@ -611,6 +697,7 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
     if (!c->lut) c->lut = new YkLutState();
     YkLutState* S = c->lut;
     if (!S->ptab) YK_HIP(c, hipMalloc(&S->ptab, (size_t)LUT_MAXPAT * 48 * 8 * sizeof(uint2)));
+    if (!S->ptabM) YK_HIP(c, hipMalloc(&S->ptabM, ((size_t)LUT_MAXPAT * 48 * 8 + 64) * sizeof(uint2)));
     if (!S->pairMode) YK_HIP(c, hipMalloc(&S->pairMode, (size_t)LUT_MAXPAT * 48));
     if (!S->patStart) YK_HIP(c, hipMalloc(&S->patStart, (LUT_MAXPAT + 1) * sizeof(int)));
     if (!S->posAll) YK_HIP(c, hipMalloc(&S->posAll, (size_t)LUT_MAXPAT * LUT_CUBE * sizeof(uint32_t)));
@@ -654,6 +741,11 @@ int yk_lut_load_pattern(yk_ctx* c, const uint8_t* r, const uint8_t* g, const uin
         }
         S->hPatStart.push_back((int)S->hPairMode.size());
         YK_HIP(c, hipMemcpyAsync(S->ptab, S->hPtab.data(), S->hPtab.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        // MFMA rows: bytes (-2x, -2y, -2z, a, b, 0, 0, 0) with |p|^2 = 127 a + b (both fit a signed byte); 64 zero rows behind the last pair
+        // (a short last group, groups past the end of a four-group step and the lanes of the unused half of K read them)
+        S->hPtabM.assign(S->hPtab.size() + 64, make_uint2(0u, 0u));
+        for (size_t q = 0; q < S->hPtab.size(); q++) S->hPtabM[q] = make_uint2((S->hPtab[q].x & 0x00FFFFFFu) | ((S->hPtab[q].y / 127u) << 24), S->hPtab[q].y % 127u);
+        YK_HIP(c, hipMemcpyAsync(S->ptabM, S->hPtabM.data(), S->hPtabM.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         YK_HIP(c, hipMemcpyAsync(S->pairMode, S->hPairMode.data(), S->hPairMode.size(), hipMemcpyHostToDevice, c->stream));
         YK_HIP(c, hipMemcpyAsync(S->patStart, S->hPatStart.data(), S->hPatStart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -734,7 +826,7 @@ int yk_lut_search(yk_ctx* c, int shiftX, int shiftY, int* matched) {
     const int w = c->fullW, h = c->h, nPix = (1 << shiftX) * (1 << shiftY);
     const size_t nSlots = (size_t)g.xBB * ((h + g.bigY - 1) / g.bigY) * g.bitCount, nb = (nSlots + 1023) / 1024;
     LutSlot* const slots = S->slots; uint8_t* const slotIdx = S->slotIdx; uint32_t* const sums = S->sums;    // yk_lut_start sized them
-    YkLutBank bank; bank.ptab = S->ptab; bank.pairMode = S->pairMode; bank.patStart = S->patStart; bank.pos = S->posAll; bank.fac = S->facAll;
+    YkLutBank bank; bank.ptab = S->ptab; bank.ptabM = S->ptabM; bank.pairMode = S->pairMode; bank.patStart = S->patStart; bank.pos = S->posAll; bank.fac = S->facAll;
     bank.nPat = S->nPat; bank.nPairs = (int)S->hPairMode.size();
     uint32_t nCand = 0;
     YK_HIP(c, hipMemsetAsync(S->list, 0, sizeof(uint32_t), c->stream));
