@@ -196,7 +196,7 @@ struct LutSlot { uint16_t type; uint8_t box[6]; uint8_t mode; uint8_t pixels; ui
 // ---- the pass's candidate tiles: whole tiles with at least one pixel that some plane has not covered yet.  A tile of at most 16 x 8 pixels
 // lies inside one 16x16 macro-tile, so its cells are a mask of that macro-tile's coverage words.  The others get their "not found" here: the
 // search kernel is launched for the candidates only (on the bench frame half of the 4.2 M 4x4 slots have nothing left to code, and an empty
-// workgroup still costs its dispatch).  list[0] = count (zeroed by the caller), list[1..] in any order: the results go to per-slot records.
+// workgroup still costs its dispatch).  list[0] = count (zeroed by the caller), then {slot, x0 | y0 << 16} pairs from word 2 on in any order: the results go to per-slot records.
 __global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __restrict__ cov, size_t covStride, int mtW, LutGeo g, int w, int h, size_t nSlots,
                                                            LutSlot* __restrict__ slots, uint32_t* __restrict__ list) {
     __shared__ uint32_t s_tmp[32], s_base;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __res
     // microsecond, one per wave of 64 slots made this kernel 0.3 ms for the 4x4 pass
     const size_t pos0 = ((size_t)blockIdx.x * 1024 + threadIdx.x) * 4;
     const int TX = 1 << g.sx, TY = 1 << g.sy;
-    uint32_t cand = 0;
+    uint32_t cand = 0, xy[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const size_t pos = pos0 + r;
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __res
             for (int q = 0; q < (TY >> 2); q++) mask |= row << ((((y0 >> 2) & 3) + q) * 4);
             c = (~((uint32_t)cov[mt] & cov[covStride + mt] & cov[2 * covStride + mt]) & mask) != 0u;
         }
+        xy[r] = (uint32_t)x0 | ((uint32_t)y0 << 16);
         if (c) cand |= 1u << r; else slots[pos].found = 0;
     }
     uint32_t tot;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(1024) void yk_lut_list_kernel(const uint16_t* __res
     __syncthreads();
     uint32_t o = 1u + s_base + ex;
 #pragma unroll
-    for (int r = 0; r < 4; r++) if ((cand >> r) & 1u) list[o++] = (uint32_t)(pos0 + r);
+    for (int r = 0; r < 4; r++) if ((cand >> r) & 1u) reinterpret_cast<uint2*>(list)[o++] = make_uint2((uint32_t)(pos0 + r), xy[r]);   // the search does not divide again
 }
 
 // ---- one workgroup per tile: 128 threads for the 128-pixel shapes, one wave for the others -------------------------------------------
@@ -274,12 +275,9 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     __shared__ uint2 s_sel[48];                                             // cell and back-swap selectors of every orientation
     constexpr int TX = 1 << SX, TY = 1 << SY, nPix = TX * TY, NT = nPix > 64 ? 128 : 64;             // the shape is a template parameter: shuffle widths, copies and loops are constants
     const int t = threadIdx.x;
-    const uint32_t pos = list[1 + blockIdx.x];                               // the candidate tiles of the pass (yk_lut_list_kernel)
-    constexpr int bigX = SX == 2 ? 32 : 64, bigY = SY == 2 ? 32 : 64, tilesPerRow = bigX >> SX, bitCount = tilesPerRow * (bigY >> SY);      // yk_lut_geo: powers of two
-    const uint32_t blk = pos / (uint32_t)bitCount, tt = pos % (uint32_t)bitCount;
-    const int x0 = (int)(blk % (uint32_t)g.xBB) * bigX + (int)(tt % (uint32_t)tilesPerRow) * TX;
-    const int y0 = (int)(blk / (uint32_t)g.xBB) * bigY + (int)(tt / (uint32_t)tilesPerRow) * TY;
-    if (x0 + TX > w || y0 + TY > h) { if (t == 0) slots[pos].found = 0; return; }             // partial tiles are never tried (:6304, :6311)
+    const uint2 cand = reinterpret_cast<const uint2*>(list)[1 + blockIdx.x];  // the candidate tiles of the pass with their origins (yk_lut_list_kernel)
+    const uint32_t pos = cand.x;
+    const int x0 = (int)(cand.y & 0xFFFFu), y0 = (int)(cand.y >> 16);       // whole tiles only: partial ones never enter the list (:6304, :6311)
     if (t == 0) s_csq = 0;
     // buildBBox3D (:132-193): a pixel is out when all three planes already cover it; the box spans the others
     const int tp = t & (nPix - 1);                                          // the thread's pixel; the first nPix threads are the tile, the others copies
@@ -355,9 +353,9 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
     // with its eight transformed points in registers (the next round's are loaded under this round's arithmetic), the pixels come as LDS
     // broadcasts: 8 dot products + 4 min3 + 1 add per pixel and lane.
     const int nPairs = bank.nPairs;
-    if constexpr (nPix >= 64) {
-        // Tiles of 64 pixels and more: the (point, pixel) products on the matrix cores (with one chunk of 32 pixels per tile the per-group sums and
-        // table loads cost more than the products save: 8x4 / 4x8 tiles took 1.89 ms instead of 1.62).  v_mfma_i32_32x32x16_i8 with rows = the 32 points of four
+    if constexpr (nPix >= 32) {
+        // Tiles of 32 pixels and more: the (point, pixel) products on the matrix cores (a 4x4 tile would fill half of the 32 columns: it keeps the
+        // v_dot4 path below).  v_mfma_i32_32x32x16_i8 with rows = the 32 points of four
         // pairs, columns = 32 pixels, K = (x, y, z, 127, 1) against (-2 px, -2 py, -2 pz, a, b), |p|^2 = 127 a + b: D[point][pixel] = |p|^2 - 2 c.p.
         // Rows are ordered so that a lane's sixteen results (rows 8 b + 4 h + r of column lane & 31, h = lane >> 5; layout checked on the part by
         // tools/ubench/mfma_i8_layout.hip) are ALL eight points of two pairs: pair 2 h + (b >> 1), point 4 (b & 1) + r -- the minimum over a pair's
@@ -805,7 +803,7 @@ int yk_lut_start(yk_ctx* c) {
         YK_HIP(c, hipMalloc(&S->slots, maxSlots * sizeof(LutSlot)));
         YK_HIP(c, hipMalloc(&S->slotIdx, (size_t)(w + 64) * (h + 64)));                      // slots x pixels per tile = whole swizzle blocks (64 x 64 at most), any shape
         YK_HIP(c, hipMalloc(&S->sums, (5 * ((maxSlots + 1023) / 1024) + 16) * sizeof(uint32_t)));
-        YK_HIP(c, hipMalloc(&S->list, (maxSlots + 1) * sizeof(uint32_t)));
+        YK_HIP(c, hipMalloc(&S->list, (maxSlots + 1) * sizeof(uint2)));
         S->capTiles = capTiles; S->capPix = capPix; S->capW = w; S->capH = h;
     }
     for (int k = 0; k < 6; k++) YK_HIP(c, hipMemsetAsync(S->map[k], 0, S->mapBytes[k] + 16, c->stream));
