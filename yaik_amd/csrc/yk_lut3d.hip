@@ -123,12 +123,30 @@ static void yk_lut_point_table(const uint8_t* pts, int count, uint2 out[48 * 8])
     }
 }
 
-// a.b + c on four signed bytes.  The builtin (__builtin_amdgcn_sdot4) is selected as v_dot4c (accumulator = destination) behind a v_mov of c;
-// the three-source form takes c where it is: one VALU instruction per (pixel, point) instead of two.
-__device__ __forceinline__ int yk_dot4(int a, int b, int c) {
-    int d;
-    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+// min over a pair's eight points of |p|^2 - 2 c.p for one pixel: eight v_dot4_i32_i8 (a.b + c on four signed bytes, the three-source form: the builtin
+// __builtin_amdgcn_sdot4 is selected as v_dot4c behind a v_mov of c, two instructions per product) and the minimum tree in ONE asm statement.
+// The result of a v_dot4 must not be read by the next instructions: hipcc pads one state behind an asm statement, and with one dot product
+// per statement a build with fewer registers put the reader of the last product right behind it (one SALU instruction between) -- wrong minima
+// on some tiles, found by the 64-pattern test case; one s_nop 1 behind every product cured it.  Here every product has at least three VALU
+// instructions between itself and its reader, and what leaves the statement is the result of a v_min3.
+__device__ __forceinline__ int yk_nearest8(int a, const uint4 (&q)[4]) {
+    int out, t0, t1, t2, t3, t4, t5, t6, t7, m1, m2;
+    asm("v_dot4_i32_i8 %1, %11, %12, %13\n\t"
+        "v_dot4_i32_i8 %2, %11, %14, %15\n\t"
+        "v_dot4_i32_i8 %3, %11, %16, %17\n\t"
+        "v_dot4_i32_i8 %4, %11, %18, %19\n\t"
+        "v_dot4_i32_i8 %5, %11, %20, %21\n\t"
+        "v_dot4_i32_i8 %6, %11, %22, %23\n\t"
+        "v_dot4_i32_i8 %7, %11, %24, %25\n\t"
+        "v_dot4_i32_i8 %8, %11, %26, %27\n\t"
+        "v_min3_i32 %9, %1, %2, %3\n\t"
+        "v_min3_i32 %10, %4, %5, %6\n\t"
+        "v_min_i32 %9, %9, %10\n\t"
+        "v_min3_i32 %0, %7, %8, %9"
+        : "=&v"(out), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(m1), "=&v"(m2)
+        : "v"(a), "v"(q[0].x), "v"(q[0].y), "v"(q[0].z), "v"(q[0].w), "v"(q[1].x), "v"(q[1].y), "v"(q[1].z), "v"(q[1].w),
+          "v"(q[2].x), "v"(q[2].y), "v"(q[2].z), "v"(q[2].w), "v"(q[3].x), "v"(q[3].y), "v"(q[3].z), "v"(q[3].w));
+    return out;
 }
 
 #ifndef YK_LUT_ABLATE
@@ -257,7 +275,7 @@ constexpr YkLutSelTab yk_lut_make_sel_tab() {
 __constant__ YkLutSelTab yk_lut_sel_tab = yk_lut_make_sel_tab();
 
 template <int SX, int SY>
-__global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
+__global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void yk_lut_search_kernel(const int32_t* __restrict__ pR, const int32_t* __restrict__ pG, const int32_t* __restrict__ pB, int strideElems,
                                                             int w, int h, LutGeo g, const YkLutBank bank, uint32_t* __restrict__ covCh32, size_t covStride,
                                                             int mtW, LutSlot* __restrict__ slots, uint8_t* __restrict__ slotIdx, uint32_t* __restrict__ bitmap,
                                                             const uint32_t* __restrict__ list) {
@@ -450,13 +468,7 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) void yk_lut_searc
             uint4 qn[4];
             const bool more = pi0 + NT < nPairs;
             if (more) points(pi + NT, qn);
-            auto nearest = [&](const int a) {
-                const int d0 = yk_dot4(a, (int)q[0].x, (int)q[0].y), d1 = yk_dot4(a, (int)q[0].z, (int)q[0].w);
-                const int d2 = yk_dot4(a, (int)q[1].x, (int)q[1].y), d3 = yk_dot4(a, (int)q[1].z, (int)q[1].w);
-                const int d4 = yk_dot4(a, (int)q[2].x, (int)q[2].y), d5 = yk_dot4(a, (int)q[2].z, (int)q[2].w);
-                const int d6 = yk_dot4(a, (int)q[3].x, (int)q[3].y), d7 = yk_dot4(a, (int)q[3].z, (int)q[3].w);
-                return min(min(min(d0, d1), min(d2, d3)), min(min(d4, d5), min(d6, d7)));
-            };
+            auto nearest = [&](const int a) { return yk_nearest8(a, q); };
             int sum = 0, p0 = 0;
 #if YK_LUT_ABLATE == 1
             p0 = pixels;
