@@ -493,15 +493,32 @@ __global__ __launch_bounds__((1 << (SX + SY)) > 64 ? 128 : 64) __attribute__((am
     // GetEvaluation3D (:697-711): first minimum of sum / (samples * 1024.0f) in float.  The sums are integers below 2^21 (128 pixels x 3 x 63^2) and the
     // divisor is the same for all of them, so two different sums differ by more than 2^-21 relatively and their float quotients differ too: the first
     // minimum of the quotients is the first minimum of the integers.  A wave per pattern: key = sum << 6 | lane, one wave minimum gives both.
+    // Two patterns per step, one in each half of the wave (a pattern has at most 28 distinct orientations, see YkLutBank; one with more than 32
+    // pairs would take the whole wave).
     {
         const int l = t & 63, wv0 = __builtin_amdgcn_readfirstlane(t >> 6);
-        for (int k = wv0; k < nPat; k += NT >> 6) {
-            const int first0 = bank.patStart[k], cnt = bank.patStart[k + 1] - first0;
-            const uint32_t pm = l < cnt ? bank.pairMode[first0 + l] : 0u;     // in flight under the reduction, picked by lane number after it
-            const uint32_t key = l < cnt ? (((uint32_t)s_sum[first0 + l] << 6) | (uint32_t)l) : 0xFFFFFFFFu;
-            const uint32_t mn = yk_wave_min_u32(key);
-            const int mode = __builtin_amdgcn_readlane((int)pm, (int)(mn & 63u));
-            if (l == 0) s_mode[k] = mode;
+        for (int k = wv0 * 2; k < nPat; k += (NT >> 6) * 2) {
+            const int f0 = bank.patStart[k], f1 = bank.patStart[k + 1], f2 = k + 1 < nPat ? bank.patStart[k + 2] : f1;
+            const int cnt0 = f1 - f0, cnt1 = f2 - f1;
+            if (cnt0 <= 32 && cnt1 <= 32) {
+                const int h = l >> 5, lh = l & 31, first = h ? f1 : f0, cnt = h ? cnt1 : cnt0;
+                const uint32_t pm = lh < cnt ? bank.pairMode[first + lh] : 0u;  // in flight under the reduction, picked by lane number after it
+                uint32_t key = lh < cnt ? (((uint32_t)s_sum[first + lh] << 6) | (uint32_t)lh) : 0xFFFFFFFFu;
+                key = min(key, yk_dpp_u32<0xB1>(key)); key = min(key, yk_dpp_u32<0x4E>(key)); key = min(key, yk_dpp_u32<0x141>(key)); key = min(key, yk_dpp_u32<0x140>(key));
+                const uint32_t mn0 = min((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16));
+                const uint32_t mn1 = min((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48));
+                const int mode0 = __builtin_amdgcn_readlane((int)pm, (int)(mn0 & 31u)), mode1 = __builtin_amdgcn_readlane((int)pm, (int)(32u + (mn1 & 31u)));
+                if (l == 0) { s_mode[k] = mode0; if (cnt1) s_mode[k + 1] = mode1; }
+            } else {
+                for (int kk = k; kk < min(k + 2, nPat); kk++) {
+                    const int first0 = bank.patStart[kk], cnt = bank.patStart[kk + 1] - first0;
+                    const uint32_t pm = l < cnt ? bank.pairMode[first0 + l] : 0u;
+                    const uint32_t key = l < cnt ? (((uint32_t)s_sum[first0 + l] << 6) | (uint32_t)l) : 0xFFFFFFFFu;
+                    const uint32_t mn = yk_wave_min_u32(key);
+                    const int mode = __builtin_amdgcn_readlane((int)pm, (int)(mn & 63u));
+                    if (l == 0) s_mode[kk] = mode;
+                }
+            }
         }
     }
     __syncthreads();
