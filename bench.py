@@ -173,7 +173,7 @@ def bench_stage(args, rank, world, dist, dev, dev_index, comm_dev) -> int:
         cand = int((~cov).sum()) * 16                         # pixels of tiles with anything left to code, an upper bound of what the passes read
         alg = 12 * cand * 6                                   # every pass reads the three int32 samples of its candidate tiles' pixels once
         kname, kms, bound = "yk_lut_search_kernel (6 tile shapes)", per[6], "valu"
-        note = (f"VALU-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations x 8 points squared distances (v_dot4_i32_i8) per candidate tile; "
+        note = (f"VALU-bound, not byte-bound: <= 128 pixels x 6 patterns x 48 orientations x 8 points squared distances per candidate tile (v_mfma_i32_32x32x16_i8 for tiles of 32+ pixels, v_dot4_i32_i8 for 4x4), then four entry depths per pixel and pattern; "
                 f"{lut_matched[0]} tiles matched on this frame; algorithmic bytes = the candidate tiles' samples once per pass")
     else:
         pixn = uncovered * 3
