@@ -111,12 +111,14 @@ __device__ __forceinline__ void yk_dec_render_words(DRenderLdsN<NW>& L, const ui
     }
     __syncthreads();
     // the four corner colours of the word's tiles, once (every run of a tile used to fetch them again: 4 byte loads per 8-byte store)
-    for (int i = threadIdx.x; i < nT * 12; i += 256) {
-        const int k = i / 12, e = i - 12 * k, c = e >> 2, q = e & 3;
+    // one (unaligned) 4-byte load per corner = its three colours (the lattice array is allocated four bytes longer), not three byte loads
+    for (int i = threadIdx.x; i < nT * 4; i += 256) {
+        const int k = i >> 2, q = i & 3;
         const int x = L.xy[k][0], y = L.xy[k][1];
         if (x < 0) continue;
         const size_t li = (size_t)((y >> 2) + ((q & 2) ? dy : 0)) * latW + (x >> 2) + ((q & 1) ? dx : 0);
-        L.c[k][c][q] = mapRGB[li * 3 + c];
+        uint32_t rgb; __builtin_memcpy(&rgb, mapRGB + li * 3, 4);
+        L.c[k][0][q] = (uint8_t)rgb; L.c[k][1][q] = (uint8_t)(rgb >> 8); L.c[k][2][q] = (uint8_t)(rgb >> 16);
     }
     __syncthreads();
     if (GW == 8 && YK_DEC_ROWPAIR) {
@@ -791,7 +793,7 @@ int yk_decode_begin(yk_ctx* c, int w, int h) {
         const int stride4 = (w + 15) >> 4;
         c->dTile4Size = (size_t)((stride4 << 2) * (((h + 7) >> 3) << 1)) >> 3;
         YK_HIP(c, hipMalloc(&c->dPlanes, c->dPlaneSize * 3));
-        YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3));
+        YK_HIP(c, hipMalloc(&c->dMapRGB, lat * 3 + 4));                              // + 4: the render reads a corner's three bytes as one word
         YK_HIP(c, hipMalloc(&c->dLatticeOwner, lat * 4));
         YK_HIP(c, hipMalloc(&c->dLoaded, lat));
         YK_HIP(c, hipMalloc(&c->dTile4, ((3 * c->dTile4Size + 3) & ~(size_t)3) + 4));   // three planes once the masks are split
