@@ -60,7 +60,7 @@ static int yk_alloc_image(yk_ctx* c) {
     YK_HIP(c, hipMalloc(&B.keep, fs.keep * F + 16));
     YK_HIP(c, hipMalloc(&B.bounds, 16 * sizeof(int32_t) * F));
     {
-        const size_t nUnits = (size_t)((c->fullW / 4 + 255) / 256) * c->mtH, nGroups = (nUnits + 63) / 64;
+        const size_t nUnits = (size_t)((c->fullW / 4 + 63) / 64) * c->mtH, nGroups = (nUnits + 63) / 64;     // sized for the smallest unit yk_alpha_kernel may use (64 int4 per segment)
         YK_HIP(c, hipMalloc(&c->alphaUnitBox, (nUnits + nGroups) * F * 4 * sizeof(int) + 16));
         YK_HIP(c, hipMalloc(&c->alphaArrive, (nGroups + 1) * F * sizeof(uint32_t) + 16));
         YK_HIP(c, hipMemset(c->alphaArrive, 0, (nGroups + 1) * F * sizeof(uint32_t) + 16));

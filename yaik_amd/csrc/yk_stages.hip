@@ -32,14 +32,18 @@ typedef int yk_i4 __attribute__((ext_vector_type(4)));
 #ifndef YK_ALPHA_INFLIGHT
 #define YK_ALPHA_INFLIGHT 8                                                  // 16-byte loads a lane has in flight (two batches per unit)
 #endif
-__global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h, int y0,
+#ifndef YK_ALPHA_THREADS
+#define YK_ALPHA_THREADS 256                                                 // 256: a unit = 1024 pixels x 16 rows (four waves); 64: 256 pixels x 16 rows (one wave per workgroup)
+#endif
+#define YK_ALPHA_WAVES (YK_ALPHA_THREADS / 64)
+__global__ __launch_bounds__(YK_ALPHA_THREADS) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h, int y0,
                                                        uint8_t* __restrict__ keep0, int mtW, int mtH, int32_t* __restrict__ bounds,
                                                        int nFrames, unsigned long long planeStride, unsigned long long keepStride,
                                                        int* __restrict__ unitBox0, uint32_t* __restrict__ arrive0) {
-    __shared__ int s_box[4][2];
+    __shared__ int s_box[YK_ALPHA_WAVES][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
-    const int nSeg = (vecPerRow + 255) >> 8;                     // 256 int4 = 1024 pixels per segment
+    const int nSeg = (vecPerRow + YK_ALPHA_THREADS - 1) / YK_ALPHA_THREADS;   // YK_ALPHA_THREADS int4 per segment
     const int nUnits = nSeg * mtH, nGroups = (nUnits + 63) >> 6;
     for (long long uu = blockIdx.x; uu < (long long)nUnits * nFrames; uu += gridDim.x) {
         const int f = (int)(uu / nUnits), u = (int)(uu - (long long)f * nUnits);
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict
         int* unitBox = unitBox0 + (size_t)f * (nUnits + nGroups) * 4;
         uint32_t* arrive = arrive0 + (size_t)f * (nGroups + 1);
         const int ty = u / nSeg, seg = u - ty * nSeg;
-        const int xv = seg * 256 + (int)threadIdx.x;
+        const int xv = seg * YK_ALPHA_THREADS + (int)threadIdx.x;
         const int32_t* col = alpha + (size_t)(ty * 16) * strideElems + (size_t)xv * 4;
         const bool inX = xv < vecPerRow;
         int nz = 0;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict
         // the unit's box of kept tiles (tile columns; its tile row is ty)
         const unsigned long long kb64 = __ballot(tileLane && kept && tx < mtW);
         if (lane == 0) {
-            const int t0 = seg * 64 + wv * 16;
+            const int t0 = seg * (YK_ALPHA_THREADS / 4) + wv * 16;
             s_box[wv][0] = kb64 ? t0 + ((__ffsll((long long)kb64) - 1) >> 2) : 0x7FFFFFFF;
             s_box[wv][1] = kb64 ? t0 + ((63 - __clzll((long long)kb64)) >> 2) : -1;
         }
@@ -105,8 +109,9 @@ __global__ __launch_bounds__(256) void yk_alpha_kernel(const int32_t* __restrict
             const int g = u >> 6, inGroup = min(64, nUnits - (g << 6));
             uint32_t lastOfGroup = 0;
             if (lane == 0) {
-                const int lo = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-                const int hi = max(max(s_box[0][1], s_box[1][1]), max(s_box[2][1], s_box[3][1]));
+                int lo = s_box[0][0], hi = s_box[0][1];
+#pragma unroll
+                for (int k = 1; k < YK_ALPHA_WAVES; k++) { lo = min(lo, s_box[k][0]); hi = max(hi, s_box[k][1]); }
                 const bool any = hi >= 0;
                 putBox(u, any ? lo * 16 : 9999999, any ? y0 + ty * 16 : 9999999, any ? hi * 16 + 16 : -1, any ? y0 + ty * 16 + 16 : -1);
                 lastOfGroup = __hip_atomic_fetch_add(&arrive[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)inGroup - 1u ? 1u : 0u;
@@ -296,9 +301,10 @@ int yk_launch_alpha(yk_ctx* c, bool batch) {
     uint8_t* keep = batch ? c->B.keep : c->keep;
     int32_t* bounds = batch ? c->B.bounds : c->bounds;
     const int32_t* alpha = batch ? c->B.plane[3] : c->plane[3];
-    const int nSeg = (c->fullW / 4 + 255) / 256;
+    const int nSeg = (c->fullW / 4 + YK_ALPHA_THREADS - 1) / YK_ALPHA_THREADS;
     const long long nUnits = (long long)nSeg * c->mtH * F;
-    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < 4096 ? nUnits : 4096)), dim3(256), 0, c->stream, alpha, c->strideElems, c->fullW, c->h, c->y0,
+    const long long maxWG = 4096LL * (256 / YK_ALPHA_THREADS);
+    hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < maxWG ? nUnits : maxWG)), dim3(YK_ALPHA_THREADS), 0, c->stream, alpha, c->strideElems, c->fullW, c->h, c->y0,
                        keep, c->mtW, c->mtH, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep, c->alphaUnitBox, c->alphaArrive);
     YK_HIP(c, hipGetLastError());
     c->boundsOff = 8;                                           // whole image / batch: the accumulators are the box; a stripe caller replaces it (yk_alpha_finish)
