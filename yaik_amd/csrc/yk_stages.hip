@@ -36,50 +36,64 @@ typedef int yk_i4 __attribute__((ext_vector_type(4)));
 #define YK_ALPHA_THREADS 256                                                 // 256: a unit = 1024 pixels x 16 rows (four waves); 64: 256 pixels x 16 rows (one wave per workgroup)
 #endif
 #define YK_ALPHA_WAVES (YK_ALPHA_THREADS / 64)
+#ifndef YK_ALPHA_ROWS
+#define YK_ALPHA_ROWS 2                                                      // rows of 16x16 tiles per unit
+#endif
 __global__ __launch_bounds__(YK_ALPHA_THREADS) void yk_alpha_kernel(const int32_t* __restrict__ alpha0, int strideElems, int w, int h, int y0,
                                                        uint8_t* __restrict__ keep0, int mtW, int mtH, int32_t* __restrict__ bounds,
                                                        int nFrames, unsigned long long planeStride, unsigned long long keepStride,
                                                        int* __restrict__ unitBox0, uint32_t* __restrict__ arrive0) {
-    __shared__ int s_box[YK_ALPHA_WAVES][2];
+    __shared__ int s_box[YK_ALPHA_WAVES][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int vecPerRow = w >> 2;                                // int4 per image row (w is a multiple of 8)
     const int nSeg = (vecPerRow + YK_ALPHA_THREADS - 1) / YK_ALPHA_THREADS;   // YK_ALPHA_THREADS int4 per segment
-    const int nUnits = nSeg * mtH, nGroups = (nUnits + 63) >> 6;
+    // a unit = YK_ALPHA_ROWS rows of tiles of one segment: the arrival protocol at its end (3-5 us in which the first wave keeps a slot of its SIMD)
+    // is paid once per 2 x 16 rows, and the 2048 units of an 8192 x 8192 frame are exactly one round of resident workgroups
+    const int nRowUnits = (mtH + YK_ALPHA_ROWS - 1) / YK_ALPHA_ROWS;
+    const int nUnits = nSeg * nRowUnits, nGroups = (nUnits + 63) >> 6;
     for (long long uu = blockIdx.x; uu < (long long)nUnits * nFrames; uu += gridDim.x) {
         const int f = (int)(uu / nUnits), u = (int)(uu - (long long)f * nUnits);
         const int32_t* alpha = alpha0 + (size_t)f * planeStride;
         uint8_t* keep = keep0 + (size_t)f * keepStride;
         int* unitBox = unitBox0 + (size_t)f * (nUnits + nGroups) * 4;
         uint32_t* arrive = arrive0 + (size_t)f * (nGroups + 1);
-        const int ty = u / nSeg, seg = u - ty * nSeg;
+        const int tyU = u / nSeg, seg = u - tyU * nSeg;
         const int xv = seg * YK_ALPHA_THREADS + (int)threadIdx.x;
-        const int32_t* col = alpha + (size_t)(ty * 16) * strideElems + (size_t)xv * 4;
         const bool inX = xv < vecPerRow;
-        int nz = 0;
-#pragma unroll
-        for (int kb = 0; kb < 16 / YK_ALPHA_INFLIGHT; kb++) {
-            yk_i4 a[YK_ALPHA_INFLIGHT];
-#pragma unroll
-            for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) {
-                const int y = ty * 16 + kb * YK_ALPHA_INFLIGHT + k;
-                a[k] = (yk_i4){0, 0, 0, 0};
-                if (inX && y < h) a[k] = __builtin_nontemporal_load(reinterpret_cast<const yk_i4*>(col + (size_t)(kb * YK_ALPHA_INFLIGHT + k) * strideElems));
-            }
-#pragma unroll
-            for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) nz |= a[k].x | a[k].y | a[k].z | a[k].w;
-        }
-        const unsigned long long b = __ballot(nz != 0);
         const bool tileLane = (lane & 3) == 0;
-        const bool kept = ((b >> (lane & ~3)) & 0xFULL) != 0;
         const int tx = xv >> 2;
-        if (tileLane && tx < mtW) keep[(size_t)ty * mtW + tx] = kept ? 1 : 0;
-        // the unit's box of kept tiles (tile columns; its tile row is ty)
-        const unsigned long long kb64 = __ballot(tileLane && kept && tx < mtW);
-        if (lane == 0) {
-            const int t0 = seg * (YK_ALPHA_THREADS / 4) + wv * 16;
-            s_box[wv][0] = kb64 ? t0 + ((__ffsll((long long)kb64) - 1) >> 2) : 0x7FFFFFFF;
-            s_box[wv][1] = kb64 ? t0 + ((63 - __clzll((long long)kb64)) >> 2) : -1;
+        int colLo = 0x7FFFFFFF, colHi = -1, rowLo = 0x7FFFFFFF, rowHi = -1;      // wave-uniform: kept tile columns / rows of this wave's share of the unit
+#pragma unroll
+        for (int r = 0; r < YK_ALPHA_ROWS; r++) {
+            const int ty = tyU * YK_ALPHA_ROWS + r;
+            if (ty >= mtH) break;
+            const int32_t* col = alpha + (size_t)(ty * 16) * strideElems + (size_t)xv * 4;
+            int nz = 0;
+#pragma unroll
+            for (int kb = 0; kb < 16 / YK_ALPHA_INFLIGHT; kb++) {
+                yk_i4 a[YK_ALPHA_INFLIGHT];
+#pragma unroll
+                for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) {
+                    const int y = ty * 16 + kb * YK_ALPHA_INFLIGHT + k;
+                    a[k] = (yk_i4){0, 0, 0, 0};
+                    if (inX && y < h) a[k] = __builtin_nontemporal_load(reinterpret_cast<const yk_i4*>(col + (size_t)(kb * YK_ALPHA_INFLIGHT + k) * strideElems));
+                }
+#pragma unroll
+                for (int k = 0; k < YK_ALPHA_INFLIGHT; k++) nz |= a[k].x | a[k].y | a[k].z | a[k].w;
+            }
+            const unsigned long long b = __ballot(nz != 0);
+            const bool kept = ((b >> (lane & ~3)) & 0xFULL) != 0;
+            if (tileLane && tx < mtW) keep[(size_t)ty * mtW + tx] = kept ? 1 : 0;
+            // the kept tiles of this row (tile columns of this wave's 16 tiles)
+            const unsigned long long kb64 = __ballot(tileLane && kept && tx < mtW);
+            if (kb64) {
+                const int t0 = seg * (YK_ALPHA_THREADS / 4) + wv * 16;
+                colLo = min(colLo, t0 + ((__ffsll((long long)kb64) - 1) >> 2));
+                colHi = max(colHi, t0 + ((63 - __clzll((long long)kb64)) >> 2));
+                rowLo = min(rowLo, ty); rowHi = max(rowHi, ty);
+            }
         }
+        if (lane == 0) { s_box[wv][0] = colLo; s_box[wv][1] = colHi; s_box[wv][2] = rowLo; s_box[wv][3] = rowHi; }
         __syncthreads();
         // Only the first wave takes part in the arrival protocol (its round trips -- store acknowledged, then one or two returning atomics -- are
         // 4-5 us at the end of a 20 us workgroup); the other three go on (to their next unit, or out).  s_box is read before anything slow, and the
@@ -109,11 +123,11 @@ __global__ __launch_bounds__(YK_ALPHA_THREADS) void yk_alpha_kernel(const int32_
             const int g = u >> 6, inGroup = min(64, nUnits - (g << 6));
             uint32_t lastOfGroup = 0;
             if (lane == 0) {
-                int lo = s_box[0][0], hi = s_box[0][1];
+                int lo = s_box[0][0], hi = s_box[0][1], rlo = s_box[0][2], rhi = s_box[0][3];
 #pragma unroll
-                for (int k = 1; k < YK_ALPHA_WAVES; k++) { lo = min(lo, s_box[k][0]); hi = max(hi, s_box[k][1]); }
+                for (int k = 1; k < YK_ALPHA_WAVES; k++) { lo = min(lo, s_box[k][0]); hi = max(hi, s_box[k][1]); rlo = min(rlo, s_box[k][2]); rhi = max(rhi, s_box[k][3]); }
                 const bool any = hi >= 0;
-                putBox(u, any ? lo * 16 : 9999999, any ? y0 + ty * 16 : 9999999, any ? hi * 16 + 16 : -1, any ? y0 + ty * 16 + 16 : -1);
+                putBox(u, any ? lo * 16 : 9999999, any ? y0 + rlo * 16 : 9999999, any ? hi * 16 + 16 : -1, any ? y0 + rhi * 16 + 16 : -1);
                 lastOfGroup = __hip_atomic_fetch_add(&arrive[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)inGroup - 1u ? 1u : 0u;
             }
             if (__builtin_amdgcn_readfirstlane((int)lastOfGroup)) {                  // the group's 64 boxes -> its group box (one round trip, anywhere in the launch)
@@ -302,7 +316,7 @@ int yk_launch_alpha(yk_ctx* c, bool batch) {
     int32_t* bounds = batch ? c->B.bounds : c->bounds;
     const int32_t* alpha = batch ? c->B.plane[3] : c->plane[3];
     const int nSeg = (c->fullW / 4 + YK_ALPHA_THREADS - 1) / YK_ALPHA_THREADS;
-    const long long nUnits = (long long)nSeg * c->mtH * F;
+    const long long nUnits = (long long)nSeg * ((c->mtH + YK_ALPHA_ROWS - 1) / YK_ALPHA_ROWS) * F;
     const long long maxWG = 4096LL * (256 / YK_ALPHA_THREADS);
     hipLaunchKernelGGL(yk_alpha_kernel, dim3((unsigned)(nUnits < maxWG ? nUnits : maxWG)), dim3(YK_ALPHA_THREADS), 0, c->stream, alpha, c->strideElems, c->fullW, c->h, c->y0,
                        keep, c->mtW, c->mtH, bounds, F, (unsigned long long)c->fs.plane, (unsigned long long)c->fs.keep, c->alphaUnitBox, c->alphaArrive);
