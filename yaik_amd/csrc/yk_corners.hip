@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void yk_corner_owner_kernel(const CornerPlan p
 // block) = byte offset of the thread's first owned corner; a thread walks its tiles in bit order = the reference's scan order.
 template <bool EMIT>
 __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const CornerPlan pl, int w, int latW,
-                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums, uint8_t* __restrict__ perThread,
+                                                                const uint32_t* __restrict__ owner, uint32_t* __restrict__ blockSums, uint32_t* __restrict__ perThread,
                                                                 const int32_t* const __restrict__ pR, const int32_t* const __restrict__ pG,
                                                                 const int32_t* const __restrict__ pB, int strideElems,
                                                                 uint8_t* __restrict__ out0, size_t region, uint32_t* __restrict__ edgeIdx, int latH, int hAvail) {
@@ -101,38 +101,47 @@ __global__ __launch_bounds__(1024) void yk_corner_stream_kernel(const CornerPlan
     const uint32_t byte = bi < nBytes ? reinterpret_cast<const uint8_t*>(pl.bm[pass])[bi] : 0u;
     const PassGeo g = yk_pass_geo(pass, w);
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    uint32_t cnt = 0;
-    if (EMIT) cnt = bi < nBytes ? perThread[ti] : 0u;
+    // COUNT leaves the thread's ownership bits (4 per tile slot) for EMIT, which then neither repeats the 32 owner look-ups nor waits for them
+    uint32_t cnt = 0, ownBits = 0;
+    if (EMIT) { ownBits = bi < nBytes ? perThread[ti] : 0u; cnt = (uint32_t)__popc(ownBits); }
     uint32_t own[8];
     int tx[8], ty[8];
     if (!EMIT || cnt) {
-        uint32_t o[8][4];
         // the 8 slots of a byte lie in one swizzle block (every block holds a multiple of 8 tiles); tiles per row / per block are powers of two
         const uint32_t pos0 = bi * 8u, blk = pos0 / (uint32_t)g.bitCount, t0 = pos0 % (uint32_t)g.bitCount;
         const int bx0 = (int)(blk % (uint32_t)g.xBB) * g.bigX, by0 = (int)(blk / (uint32_t)g.xBB) * g.bigY;
         const int tprShift = __ffs(g.tilesPerRow) - 1;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const bool set = (byte >> k) & 1u;
             const uint32_t t = t0 + (uint32_t)k;
             tx[k] = bx0 + (int)((t & (uint32_t)(g.tilesPerRow - 1)) << g.sx); ty[k] = by0 + (int)((t >> tprShift) << g.sy);
-            const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
-            const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
-            o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
         }
+        if (EMIT) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
-            const bool set = (byte >> k) & 1u;
-            own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+            for (int k = 0; k < 8; k++) own[k] = (ownBits >> (4 * k)) & 15u;
+        } else {
+            uint32_t o[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool set = (byte >> k) & 1u;
+                const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
+                const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
+                o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+                const bool set = (byte >> k) & 1u;
+                own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+            }
         }
     }
     if (!EMIT) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) cnt += (uint32_t)__popc(own[k]);
+        for (int k = 0; k < 8; k++) { cnt += (uint32_t)__popc(own[k]); ownBits |= own[k] << (4 * k); }
         uint32_t tot;
         yk_block_exscan(cnt, s_tmp, &tot);
-        if (bi < nBytes) perThread[ti] = (uint8_t)cnt;
+        if (bi < nBytes) perThread[ti] = ownBits;
         if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
         return;
     }
@@ -238,11 +247,11 @@ int yk_launch_corners(yk_ctx* c) {
         pl.blockStart[p + 1] = pl.blockStart[p] + ((pl.wordStart[p + 1] - pl.wordStart[p]) * 4u + 1023u) / 1024u;   // 1024 bitmap bytes per workgroup
     }
     const size_t nbTot = pl.blockStart[7], nWordsTot = pl.wordStart[7];
-    // scratch: [block sums | 7 totals (+ pad) | corners per thread (one byte per bitmap byte)]
-    if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64 + nWordsTot; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
+    // scratch: [block sums | 7 totals (+ pad) | ownership bits per thread (one word per bitmap byte)]
+    if (!c->cornerScratch) { c->cornerScratchElems = nbTot + 64 + nWordsTot * 4; YK_HIP(c, hipMalloc(&c->cornerScratch, c->cornerScratchElems * 4)); }
     uint32_t* blockSums = c->cornerScratch;
     uint32_t* totalDev = c->cornerScratch + nbTot;
-    uint8_t* perThread = reinterpret_cast<uint8_t*>(c->cornerScratch + nbTot + 64);
+    uint32_t* perThread = c->cornerScratch + nbTot + 64;
     if (!c->cornerEdgeIdx) YK_HIP(c, hipMalloc(&c->cornerEdgeIdx, (size_t)latW * 2 * 4));
     { int rc = yk_stage_begin(c, YK_STAGE_CORNERS); if (rc) return rc; }
     YK_HIP(c, hipMemsetAsync(c->cornerEdgeIdx, 0xFF, (size_t)latW * 2 * 4, c->stream));

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void yk_decall_owner_kernel(const DecPlan pl, 
 // non-empty words are appended to the pass's render list.
 template <bool EMIT>
 __global__ __launch_bounds__(1024) void yk_decall_stream_kernel(const DecPlan pl, int w, int h, int latW, uint8_t* __restrict__ loaded, const uint32_t* __restrict__ owner,
-                                                                uint32_t* __restrict__ blockSums, uint32_t* __restrict__ blockWords, uint8_t* __restrict__ perThread,
+                                                                uint32_t* __restrict__ blockSums, uint32_t* __restrict__ blockWords, uint32_t* __restrict__ perThread,
                                                                 uint8_t* __restrict__ mapRGB, uint32_t* __restrict__ wordList, uint32_t factor) {
     __shared__ uint32_t s_tmp[32];
     const int pass = yk_dplan_find(pl.blockStart, blockIdx.x);
@@ -296,23 +296,32 @@ __global__ __launch_bounds__(1024) void yk_decall_stream_kernel(const DecPlan pl
     }
     const DPassGeo g = yk_dpass_geo(pl.sx[pass], pl.sy[pass], w);
     const int dx = 1 << (g.sx - 2), dy = 1 << (g.sy - 2);
-    uint32_t cnt = 0;
-    if (EMIT) cnt = bi < nBytes ? perThread[ti] : 0u;
+    // COUNT leaves the thread's ownership bits (4 per tile slot) for EMIT, which then neither repeats the 32 owner look-ups nor waits for them
+    uint32_t cnt = 0, ownBits = 0;
+    if (EMIT) { ownBits = bi < nBytes ? perThread[ti] : 0u; cnt = (uint32_t)__popc(ownBits); }
     uint32_t own[8];
     int tx[8], ty[8];
     if ((!EMIT && byte) || cnt) {
-        uint32_t o[8][4];
         const DByteGeo b = yk_dbyte_geo(g, bi);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t t = b.t0 + (uint32_t)k;
             tx[k] = b.bx0 + (int)((t & (uint32_t)b.tprMask) << g.sx); ty[k] = b.by0 + (int)((t >> b.tprShift) << g.sy);
-            const bool set = ((byte >> k) & 1u) && !(tx[k] + (1 << g.sx) > w || ty[k] + (1 << g.sy) > h);
-            const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
-            const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
-            o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
-            const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
-            own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+        }
+        if (EMIT) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) own[k] = (ownBits >> (4 * k)) & 15u;
+        } else {
+            uint32_t o[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool set = ((byte >> k) & 1u) && !(tx[k] + (1 << g.sx) > w || ty[k] + (1 << g.sy) > h);
+                const size_t l0 = set ? (size_t)(ty[k] >> 2) * latW + (tx[k] >> 2) : 0;
+                const size_t ddx = set ? dx : 0, ddy = set ? (size_t)dy * latW : 0;
+                o[k][0] = owner[l0]; o[k][1] = owner[l0 + ddx]; o[k][2] = owner[l0 + ddy]; o[k][3] = owner[l0 + ddy + ddx];
+                const uint32_t key = ((uint32_t)pass << 27) | ((bi * 8u + (uint32_t)k) << 2);
+                own[k] = set ? ((o[k][0] == (key | 0u) ? 1u : 0u) | (o[k][1] == (key | 1u) ? 2u : 0u) | (o[k][2] == (key | 2u) ? 4u : 0u) | (o[k][3] == (key | 3u) ? 8u : 0u)) : 0u;
+            }
         }
     } else {
 #pragma unroll
@@ -320,11 +329,11 @@ __global__ __launch_bounds__(1024) void yk_decall_stream_kernel(const DecPlan pl
     }
     if (!EMIT) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) cnt += (uint32_t)__popc(own[k]);
+        for (int k = 0; k < 8; k++) { cnt += (uint32_t)__popc(own[k]); ownBits |= own[k] << (4 * k); }
         uint32_t tot, totW;
         yk_block_exscan(cnt, s_tmp, &tot);
         yk_block_exscan(wordSet ? 1u : 0u, s_tmp, &totW);
-        if (bi < nBytes) perThread[ti] = (uint8_t)cnt;
+        if (bi < nBytes) perThread[ti] = ownBits;
         if (threadIdx.x == 0) { blockSums[blockIdx.x] = tot; blockWords[blockIdx.x] = totW; }
         return;
     }
@@ -907,14 +916,14 @@ int yk_decode_gradient_all_device(yk_ctx* c, int nPasses, const int* tileShiftX,
         pl.wordStart[p + 1] = pl.wordStart[p] + (uint32_t)((nb + 3) / 4);
     }
     const size_t nbTot = pl.blockStart[7], nBytesTot = pl.byteStart[7], nWordsTot = pl.wordStart[7];
-    // scratch: [corners per block | words per block | words listed per pass | corners per bitmap byte | render lists]
-    const size_t oS = 0, oW = oS + nbTot * 4, oP = oW + nbTot * 4, oT = oP + 64, oL = (oT + nBytesTot + 15) & ~(size_t)15;
+    // scratch: [corners per block | words per block | words listed per pass | ownership bits per bitmap byte (one word) | render lists]
+    const size_t oS = 0, oW = oS + nbTot * 4, oP = oW + nbTot * 4, oT = oP + 64, oL = (oT + nBytesTot * 4 + 15) & ~(size_t)15;
     { const int rc = yk_dec_scratch(c, oL + nWordsTot * 4 + 64); if (rc) return rc; }
     uint8_t* S = c->dScratch;
     uint32_t* blockSums = reinterpret_cast<uint32_t*>(S + oS);
     uint32_t* blockWords = reinterpret_cast<uint32_t*>(S + oW);
     uint32_t* passWords = reinterpret_cast<uint32_t*>(S + oP);
-    uint8_t* perThread = S + oT;
+    uint32_t* perThread = reinterpret_cast<uint32_t*>(S + oT);
     uint32_t* wordList = reinterpret_cast<uint32_t*>(S + oL);
     const uint32_t factor = remapRange > 0 ? (uint32_t)((255u << 16) / (uint32_t)remapRange) : 0u;
     YK_HIP(c, hipMemsetAsync(c->dLatticeOwner, 0xFF, lat * 4, c->stream));
